@@ -1,0 +1,119 @@
+/* vfml.h — C ABI of libvfml_hip.so, the MI355X (gfx950) kernels behind the multi-frame
+ * optical-flow hot path.
+ *
+ * The reference (IvanPopov/video-flow-ml) has no FFI of its own: its boundary is the Python
+ * object protocol `build_network(cfg)(images, {})` (processing/videoflow_core.py:28,101,188).
+ * Everything below that call is PyTorch-CUDA library work (cuDNN conv, cuBLAS bmm, grid_sample,
+ * unfold, softmax) launched by the un-vendored VideoFlow submodule.  Each entry point here
+ * replaces one of those implicit library ops; the Python host
+ * (video-flow-ml_amd/vfml/hip.py) binds them with ctypes and sequences them.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA tensor .data_ptr()) unless
+ *     the name says host; buffers are borrowed for the duration of the call only;
+ *   - activations are NHWC fp32: tensor[n][y][x][c], `ld` = floats between consecutive pixels
+ *     (>= channels; lets a kernel read or write a channel slice of a wider buffer);
+ *   - channel counts, ld values and base pointers are multiples of 4 floats / 16 bytes;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - return 0 on success, non-zero on a rejected argument or launch error
+ *     (text from vfml_last_error(), thread-local).  Nothing is launched on error.
+ */
+#ifndef VFML_H
+#define VFML_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFML_ABI_VERSION 1
+
+/* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + bias[c]). */
+enum {
+  VFML_EPI_NONE = 0,       /* out = v                                                        */
+  VFML_EPI_RELU = 1,       /* out = max(v, 0)                                                */
+  VFML_EPI_TANH = 2,
+  VFML_EPI_SIGMOID = 3,
+  VFML_EPI_TANH_RELU = 4,  /* c <  split: tanh(v)   else relu(v)   (cnet -> net | inp)       */
+  VFML_EPI_GRU_ZR = 5,     /* c <  split: sigmoid(v) else sigmoid(v) * aux0[p][c - split]    */
+  VFML_EPI_GRU_Q = 6,      /* out = (1 - z) * h + z * tanh(v), z = aux0[p][c], h = aux1[p][c] */
+};
+
+/* Implicit-GEMM 2-D convolution / plain GEMM on the f32 matrix cores.
+ *   out[p][co] = epi( sum_{ky,kx,ci} in(p; ky,kx)[ci] * w[co][ky][kx][ci] + bias[co] )
+ * The input is the channel-concatenation of up to two NHWC sources (in1 may be NULL).
+ * A 1x1/stride-1 conv with N*H*W = rows is a row-major GEMM  out[rows][cout] = A[rows][K]·W[cout][K]^T
+ * (used for the all-pairs correlation volume).
+ * Replaces: cuDNN conv2d + bias + activation, cuBLAS bmm. */
+typedef struct vfml_conv_desc {
+  const float* in0; int32_t c0; int32_t ld0;
+  const float* in1; int32_t c1; int32_t ld1;       /* optional second source (NULL, 0, 0)     */
+  int32_t n, h, w;                                  /* input batch / height / width            */
+  const float* weight;                              /* [cout][kh][kw][c0+c1]                   */
+  const float* bias;                                /* [cout] or NULL                          */
+  int32_t cout, kh, kw, stride, pad_h, pad_w;
+  float* out; int32_t ldo;                          /* [n][ho][wo][ldo], ho=(h+2ph-kh)/s+1     */
+  int32_t epilogue; int32_t split; float out_scale;
+  const float* aux0; int32_t ld_aux0;
+  const float* aux1; int32_t ld_aux1;
+} vfml_conv_desc;
+
+int vfml_conv2d(const vfml_conv_desc* d, void* stream);
+
+/* K1: frames -> normalised NHWC4 (4th channel zero):  dst = scale * x + shift.
+ * kind 0: src is uint8 [n][H][W][3] (values 0..255, x = u8/255 as the reference does at
+ *         processing/videoflow_processor.py:154);  kind 1: src is float32 [n][3][H][W]. */
+int vfml_frames_to_nhwc4(const void* src, int kind, int n, int H, int W,
+                         float scale, float shift, float* dst, void* stream);
+
+/* Instance norm (affine-free, eps, biased variance) over NHWC x[n][hw][c] (dense, ld == c).
+ * stats[n][c] = {mean, rstd}; workspace >= vfml_instnorm_workspace_bytes(n, hw, c).
+ * Replaces: nn.InstanceNorm2d in the encoders. */
+int64_t vfml_instnorm_workspace_bytes(int n, int hw, int c);
+int vfml_instnorm_stats(const float* x, int n, int hw, int c, float eps,
+                        float* stats, void* workspace, void* stream);
+/* out = relu( norm(x; stats) )                                  if res == NULL
+ * out = relu( res' + relu(norm(x; stats)) )                     otherwise, where
+ *       res' = res (res_stats == NULL) or norm(res; res_stats)  (down-sampled shortcut).   */
+int vfml_instnorm_apply(const float* x, const float* stats, const float* res,
+                        const float* res_stats, int n, int hw, int c, float* out, void* stream);
+
+/* 2x2/stride-2 average pooling (floor) of an NHWC map; used to build the pooled target-feature
+ * pyramid so that pyramid level l of the correlation volume is one GEMM against level-l
+ * features (avg-pool commutes with the dot product). */
+int vfml_avgpool2x2(const float* x, int n, int h, int w, int c, float* out, void* stream);
+
+/* K5: correlation lookup.  For each of nq queries (row q of every pyramid level) sample a
+ * (2r+1)^2 window around coords[q]/2^l with bilinear interpolation, zeros outside, RAFT's
+ * window order (channel i*(2r+1)+j samples x+d[i], y+d[j]).
+ *   pyr[l]     : float [nq][ld[l]]  (row = query, columns = hl[l]*wl[l] targets, row-major)
+ *   coords     : float [nq][ld_coords], x at +0, y at +1
+ *   out        : float [nq][ld_out], levels*(2r+1)^2 channels written from out
+ * Replaces: F.grid_sample(align_corners=True) x levels. */
+int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl,
+                     const int32_t* ld, int levels, int radius, int nq,
+                     const float* coords, int ld_coords, float* out, int ld_out, void* stream);
+
+/* coords1 += delta (4 floats per pixel: fwd x,y, bwd x,y); flow = coords1 - grid is written to
+ * flow_a[p*ld_a..+4] and flow_b[p*ld_b..+4] (either may be NULL).  h,w give the pixel grid,
+ * n maps. delta may be NULL (just (re)emit flow).  */
+int vfml_coords_update(float* coords1, const float* delta, int n, int h, int w,
+                       float* flow_a, int ld_a, float* flow_b, int ld_b, void* stream);
+/* coords1[p] = (x, y, x, y) */
+int vfml_coords_init(float* coords1, int n, int h, int w, void* stream);
+
+/* K8: 8x convex upsampling of one flow (2 of the 4 coords channels) of one map.
+ *   coords1: [h][w][4] of that map (flow = coords1[ch..ch+1] - grid), mask: [h][w][ld_mask]
+ *   (576 logits used: tap k (3x3, row-major) * 64 + sy*8 + sx), out: [8h][8w][2] (HWC).
+ * Replaces: softmax + F.unfold + sum + permute and the CHW->HWC permute of
+ * processing/videoflow_processor.py:185. */
+int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld_mask,
+                         int h, int w, float* out, void* stream);
+
+const char* vfml_last_error(void);
+int vfml_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+"""End-to-end parity of the HIP engine against the CPU oracle: same seeded weights, same inputs,
+mean end-point error < 1e-3 px (the tolerance BASELINE.json's north_star states)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPE_TOL = 1e-3  # px, mean over pixels of ||flow_engine - flow_oracle||_2
+
+
+def _pair(seed=0, **over):
+    from oracle import mof_oracle as mo
+    from vfml import build_network, get_cfg
+    from vfml.weights import seeded_state_dict
+    cfg, ocfg = get_cfg(), mo.get_cfg()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+        setattr(ocfg, k, v)
+    sd = seeded_state_dict(cfg, seed)
+    net = build_network(cfg)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    ora = mo.build_network(ocfg)
+    ora.load_state_dict(sd)
+    ora.eval()
+    return net, ora
+
+
+def _epe(a, b):
+    return (a - b).pow(2).sum(2).sqrt()
+
+
+@pytest.mark.parametrize("T,H,W", [(3, 128, 128), (5, 128, 192), (4, 136, 160)])
+def test_model_forward_matches_oracle(gpu, T, H, W):
+    net, ora = _pair()
+    g = torch.Generator().manual_seed(T * 1000 + H)
+    x = torch.rand(1, T, 3, H, W, generator=g)
+    ref, _ = ora(x, {})
+    got, _ = net(x.cuda(), {})
+    got = got.cpu()
+    assert got.shape == ref.shape == (1, 2 * (T - 2), 2, H, W)
+    e = _epe(got, ref)
+    assert torch.isfinite(got).all()
+    assert e.mean().item() < EPE_TOL, f"mean EPE {e.mean().item():.3e} px (max {e.max().item():.3e})"
+
+
+def test_fast_mode_config_matches_oracle(gpu):
+    """--fast overrides (reference processing/videoflow_core.py:91-94): depth 6, 3 levels, radius 3."""
+    net, ora = _pair(decoder_depth=6, corr_levels=3, corr_radius=3)
+    x = torch.rand(1, 3, 3, 128, 160, generator=torch.Generator().manual_seed(5))
+    ref, _ = ora(x, {})
+    got, _ = net(x.cuda(), {})
+    assert _epe(got.cpu(), ref).mean().item() < EPE_TOL
+
+
+def test_uint8_frames_equal_float_frames(gpu):
+    """Handing the engine u8 HWC frames (device-side /255) gives the same field as the reference's
+    host-side float conversion (processing/videoflow_processor.py:152-157)."""
+    net, _ = _pair()
+    u8 = torch.randint(0, 256, (3, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(6))
+    f = (u8.float() / 255.0).permute(0, 3, 1, 2)[None]
+    a, _ = net(f.cuda(), {})
+    a = a.clone()
+    b, _ = net.forward_u8(u8.cuda())
+    assert torch.equal(a, b)
+
+
+def test_engine_refuses_cpu_tensors():
+    from vfml import build_network, get_cfg
+    net = build_network(get_cfg())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 3, 128, 128), {})

@@ -1,0 +1,261 @@
+"""Per-kernel parity: each C-ABI entry point (include/vfml.h) against the same op of the CPU
+oracle / plain PyTorch fp32 on identical seeded inputs.  Tolerances are fp32 rounding-level."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):  # NCHW cpu -> flat NHWC device
+    return x.permute(0, 2, 3, 1).contiguous().cuda().reshape(-1)
+
+
+def from_nhwc(flat, n, h, w, c):
+    return flat.view(n, h, w, c).permute(0, 3, 1, 2).cpu()
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,stride,ph,pw,H,W,n", [
+    (4, 64, 7, 7, 2, 3, 3, 64, 80, 2),      # encoder stem (cin 3 padded to 4)
+    (64, 96, 3, 3, 2, 1, 1, 32, 40, 2),     # strided residual conv, cout not a tile multiple
+    (96, 96, 3, 3, 1, 1, 1, 17, 23, 1),     # ragged spatial size
+    (128, 256, 1, 1, 1, 0, 0, 16, 20, 3),   # 1x1
+    (64, 96, 1, 1, 2, 0, 0, 32, 40, 2),     # strided 1x1 shortcut
+    (512, 256, 1, 5, 1, 0, 2, 16, 20, 2),   # GRU horizontal
+    (512, 128, 5, 1, 1, 2, 0, 16, 20, 2),   # GRU vertical
+    (256, 4, 3, 3, 1, 1, 1, 16, 20, 3),     # flow head, 4 outputs
+    (256, 124, 3, 3, 1, 1, 1, 16, 20, 1),   # motion encoder tail
+    (648, 256, 1, 1, 1, 0, 0, 16, 20, 1),   # corr reduce (K not a multiple of 32)
+])
+def test_conv2d_matches_torch(gpu, cin, cout, kh, kw, stride, ph, pw, H, W, n):
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x, wt, b, stride=stride, padding=(ph, pw)))
+    ho, wo = ref.shape[-2:]
+    out = torch.full((n * ho * wo * cout,), float("nan"), device=gpu)
+    hip.conv2d(nhwc(x), cin, cin, n, H, W, pack_conv_weight(wt).cuda(), b.cuda(), cout, kh, kw, out, cout,
+               stride=stride, pad_h=ph, pad_w=pw, epilogue=hip.EPI_RELU)
+    got = from_nhwc(out, n, ho, wo, cout)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < 2e-6
+
+
+def test_conv2d_two_sources_slices_and_gru_epilogues(gpu):
+    """cat([r*h, x]) input from two buffers, output into a channel slice, GRU gate epilogues."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(2)
+    n, H, W = 2, 12, 20
+    h = torch.tanh(torch.randn(n, 128, H, W, generator=g))
+    x = torch.randn(n, 384, H, W, generator=g)
+    wz, wr, wq = [torch.randn(128, 512, 1, 5, generator=g) / math.sqrt(512 * 5) for _ in range(3)]
+    bz, br, bq = [torch.randn(128, generator=g) * 0.1 for _ in range(3)]
+    hx = torch.cat([h, x], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=(0, 2)))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=(0, 2)))
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq, bq, padding=(0, 2)))
+    href = (1 - z) * h + z * q
+    hx_d = nhwc(hx)
+    zr = torch.empty(n * H * W * 256, device=gpu)
+    wzr = torch.cat([pack_conv_weight(wz), pack_conv_weight(wr)]).cuda()
+    hip.conv2d(hx_d, 512, 512, n, H, W, wzr, torch.cat([bz, br]).cuda(), 256, 1, 5, zr, 256, pad_w=2,
+               epilogue=hip.EPI_GRU_ZR, split=128, aux0=hx_d, ld_aux0=512)
+    got_zr = from_nhwc(zr, n, H, W, 256)
+    assert rel_err(got_zr[:, :128], z) < 2e-6
+    assert rel_err(got_zr[:, 128:], r * h) < 2e-6
+    hip.conv2d(zr, 128, 256, n, H, W, pack_conv_weight(wq).cuda(), bq.cuda(), 128, 1, 5, hx_d, 512, in0_off=128,
+               in1=hx_d, c1=384, ld1=512, in1_off=128, pad_w=2, epilogue=hip.EPI_GRU_Q, aux0=zr, ld_aux0=256,
+               aux1=hx_d, ld_aux1=512)
+    got = from_nhwc(hx_d, n, H, W, 512)
+    assert rel_err(got[:, :128], href) < 3e-6
+    assert torch.equal(got[:, 128:], x)  # the x slice is untouched
+
+
+def test_conv2d_as_gemm_correlation(gpu):
+    """out[q][s] = <f1[q], f2[s]> / sqrt(D) with a padded leading dimension (K3)."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(3)
+    P, S, D = 300, 77, 256
+    f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
+    ld = 96
+    out = torch.zeros(P * ld, device=gpu)
+    hip.conv2d(f1.cuda().reshape(-1), D, D, 1, 1, P, f2.cuda().reshape(-1), None, S, 1, 1, out, ld,
+               out_scale=1.0 / 16.0)
+    ref = (f1.double() @ f2.double().t() / 16.0).float()
+    got = out.view(P, ld).cpu()
+    assert rel_err(got[:, :S], ref) < 2e-6
+    assert (got[:, S:] == 0).all()
+
+
+def test_conv2d_rejects_bad_arguments(gpu):
+    from vfml import hip
+    x = torch.zeros(64, device=gpu)
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        hip.conv2d(x, 3, 3, 1, 4, 4, x, None, 4, 1, 1, x, 4)
+    with pytest.raises(RuntimeError, match="ldo"):
+        hip.conv2d(x, 4, 4, 1, 4, 4, x, None, 8, 1, 1, x, 4)
+
+
+@pytest.mark.parametrize("kind", ["u8", "f32"])
+def test_frames_to_nhwc4(gpu, kind):
+    from vfml import hip
+    g = torch.Generator().manual_seed(4)
+    n, H, W = 3, 16, 24
+    u8 = torch.randint(0, 256, (n, H, W, 3), generator=g, dtype=torch.uint8)
+    x01 = (u8.float() / 255.0).permute(0, 3, 1, 2).contiguous()     # what the reference uploads
+    ref = 2.0 * x01 - 1.0
+    dst = torch.empty(n * H * W * 4, device=gpu)
+    hip.frames_to_nhwc4(u8.cuda() if kind == "u8" else x01.cuda(), n, H, W, 2.0, -1.0, dst)
+    got = dst.view(n, H, W, 4).cpu()
+    assert torch.equal(got[..., :3].permute(0, 3, 1, 2), ref)
+    assert (got[..., 3] == 0).all()
+
+
+@pytest.mark.parametrize("c,hw", [(64, 5000), (96, 333), (128, 4097)])
+def test_instnorm(gpu, c, hw):
+    from vfml import hip
+    g = torch.Generator().manual_seed(5)
+    n = 2
+    x = torch.randn(n, c, hw, 1, generator=g) * 3 + 1.5
+    res = torch.randn(n, c, hw, 1, generator=g)
+    xd, rd = nhwc(x), nhwc(res)
+    st = torch.empty(n * c * 2, device=gpu)
+    st2 = torch.empty(n * c * 2, device=gpu)
+    ws = torch.empty(hip.instnorm_workspace_bytes(n, hw, c) // 8 + 1, device=gpu, dtype=torch.float64)
+    hip.instnorm_stats(xd, n, hw, c, st, ws)
+    hip.instnorm_stats(rd, n, hw, c, st2, ws)
+    out = torch.empty_like(xd)
+    y = F.relu(F.instance_norm(x))
+    hip.instnorm_apply(xd, st, n, hw, c, out)
+    assert rel_err(from_nhwc(out, n, hw, 1, c), y) < 3e-6
+    hip.instnorm_apply(xd, st, n, hw, c, out, res=rd)
+    assert rel_err(from_nhwc(out, n, hw, 1, c), F.relu(res + y)) < 3e-6
+    hip.instnorm_apply(xd, st, n, hw, c, out, res=rd, res_stats=st2)
+    assert rel_err(from_nhwc(out, n, hw, 1, c), F.relu(F.instance_norm(res) + y)) < 3e-6
+
+
+def test_avgpool2x2_floor(gpu):
+    from vfml import hip
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 8, 7, 9, generator=g)
+    out = torch.empty(2 * 3 * 4 * 8, device=gpu)
+    hip.avgpool2x2(nhwc(x), 2, 7, 9, 8, out)
+    assert torch.allclose(from_nhwc(out, 2, 3, 4, 8), F.avg_pool2d(x, 2, 2), rtol=0, atol=1e-6)
+
+
+def _pyramid_inputs(seed, h, w, levels, nq_maps=1):
+    g = torch.Generator().manual_seed(seed)
+    P = h * w
+    corr0 = torch.randn(nq_maps * P, 1, h, w, generator=g)
+    pyr = [corr0]
+    for _ in range(levels - 1):
+        pyr.append(F.avg_pool2d(pyr[-1], 2, 2))
+    return pyr
+
+
+@pytest.mark.parametrize("radius,levels", [(4, 4), (3, 3)])
+def test_corr_lookup_matches_grid_sample(gpu, radius, levels):
+    from oracle import mof_oracle as mo
+    from vfml import hip
+    h, w = 18, 24
+    pyr = _pyramid_inputs(7, h, w, levels)
+    g = torch.Generator().manual_seed(8)
+    coords = mo.coords_grid(1, h, w) + torch.randn(1, 2, h, w, generator=g) * 6.0   # some land far outside
+    blk = mo.CorrBlock.__new__(mo.CorrBlock)
+    blk.num_levels, blk.radius, blk.pyramid = levels, radius, pyr
+    ref = blk(coords)                                        # [1, L*win, h, w]
+    P = h * w
+    hl = [p.shape[-2] for p in pyr]
+    wl = [p.shape[-1] for p in pyr]
+    ld = [(a * b + 31) // 32 * 32 for a, b in zip(hl, wl)]
+    dev = []
+    for p, l in zip(pyr, ld):
+        t = torch.full((P, l), float("nan"))
+        t[:, :p.shape[-2] * p.shape[-1]] = p.reshape(P, -1)
+        dev.append(t.cuda().reshape(-1))
+    c4 = torch.zeros(P, 4)
+    c4[:, 2:] = coords[0].permute(1, 2, 0).reshape(P, 2)     # use the (bwd) slot at +2
+    nch = levels * (2 * radius + 1) ** 2
+    out = torch.full((P * (nch + 4),), float("nan"), device=gpu)
+    hip.corr_lookup(dev, hl, wl, ld, radius, P, c4.cuda().reshape(-1), 2, 4, out, 4, nch + 4)
+    got = out.view(P, nch + 4)[:, 4:].cpu().view(h, w, nch).permute(2, 0, 1)[None]
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_corr_lookup_integer_coords_is_exact_gather(gpu):
+    """Known answer: at integer coordinates the window is a plain gather, zeros outside."""
+    from vfml import hip
+    h, w, r = 16, 16, 4
+    P = h * w
+    corr = torch.arange(P * P, dtype=torch.float32).view(P, P)
+    coords = torch.zeros(P, 4)
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    coords[:, 0], coords[:, 1] = xs.reshape(-1).float(), ys.reshape(-1).float()
+    out = torch.empty(P * 81, device=gpu)
+    hip.corr_lookup([corr.cuda().reshape(-1)], [h], [w], [P], r, P, coords.cuda().reshape(-1), 0, 4, out, 0, 81)
+    got = out.view(P, 9, 9).cpu()
+    q = 5 * w + 7
+    for i in range(9):
+        for j in range(9):
+            x, y = 7 + i - r, 5 + j - r                      # channel (i,j): x + d[i], y + d[j]
+            want = corr[q, y * w + x].item() if 0 <= x < w and 0 <= y < h else 0.0
+            assert got[q, i, j].item() == want
+
+
+def test_coords_and_upsample(gpu):
+    from oracle import mof_oracle as mo
+    from vfml import hip
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 2, 10, 12
+    coords1 = torch.empty(n * h * w * 4, device=gpu)
+    hip.coords_init(coords1, n, h, w)
+    delta = torch.randn(n, h, w, 4, generator=g)
+    flow = torch.empty(n * h * w * 4, device=gpu)
+    wide = torch.zeros(n * h * w * 8, device=gpu)
+    hip.coords_update(coords1, delta.cuda().reshape(-1), n, h, w, flow_a=flow, ld_a=4, flow_b=wide, ld_b=8,
+                      flow_b_off=4)
+    grid = mo.coords_grid(n, h, w).permute(0, 2, 3, 1)
+    c1 = torch.cat([grid + delta[..., :2], grid + delta[..., 2:]], -1)
+    assert torch.equal(coords1.view(n, h, w, 4).cpu(), c1)
+    want_flow = c1 - torch.cat([grid, grid], -1)
+    assert torch.equal(flow.view(n, h, w, 4).cpu(), want_flow)
+    assert torch.equal(wide.view(n, h, w, 8).cpu()[..., 4:], want_flow)
+    mask = torch.randn(n, 1152, h, w, generator=g) * 2
+    md = nhwc(mask)
+    for d in range(2):
+        for m in range(n):
+            out = torch.empty(8 * h * 8 * w * 2, device=gpu)
+            hip.convex_upsample(coords1, m * h * w * 4, 2 * d, md, m * h * w * 1152 + d * 576, 1152, h, w, out)
+            ref = mo.upsample_flow(want_flow[m:m + 1, ..., 2 * d:2 * d + 2].permute(0, 3, 1, 2),
+                                   mask[m:m + 1, d * 576:(d + 1) * 576])
+            got = out.view(8 * h, 8 * w, 2).permute(2, 0, 1).cpu()[None]
+            assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_upsample_uniform_mask_known_answer(gpu):
+    """Uniform logits -> every sub-pixel is the mean of the 3x3 (zero-padded) neighbourhood x8."""
+    from vfml import hip
+    h, w = 6, 7
+    coords1 = torch.empty(h * w * 4, device=gpu)
+    hip.coords_init(coords1, 1, h, w)
+    delta = torch.zeros(h, w, 4)
+    delta[..., 0] = 1.0                                       # fwd flow = (1, 0) everywhere
+    hip.coords_update(coords1, delta.cuda().reshape(-1), 1, h, w)
+    mask = torch.zeros(h * w * 576, device=gpu)
+    out = torch.empty(8 * h * 8 * w * 2, device=gpu)
+    hip.convex_upsample(coords1, 0, 0, mask, 0, 576, h, w, out)
+    got = out.view(8 * h, 8 * w, 2).cpu()
+    assert torch.allclose(got[8 * 2:8 * 3, 8 * 3:8 * 4, 0], torch.full((8, 8), 8.0), atol=1e-5)   # interior
+    assert torch.allclose(got[0:8, 0:8, 0], torch.full((8, 8), 8.0 * 4 / 9), atol=1e-5)         # corner: 4 of 9 taps
+    assert (got[..., 1] == 0).all()

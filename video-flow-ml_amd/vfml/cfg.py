@@ -1,0 +1,35 @@
+"""Model configuration bag.
+
+Stands in for `configs.multiframes_sintel_submission.get_cfg` of the VideoFlow submodule
+(imported at reference processing/videoflow_core.py:30; mutated at :88 `cfg.model` and
+:92-94 `decoder_depth / corr_levels / corr_radius` for --fast).  A plain mutable attribute bag,
+like yacs' CfgNode as the reference uses it.
+"""
+
+
+class Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __repr__(self):
+        return "Cfg(" + ", ".join(f"{k}={v!r}" for k, v in sorted(self.__dict__.items())) + ")"
+
+    def clone(self):
+        return Cfg(**self.__dict__)
+
+
+def get_cfg():
+    return Cfg(
+        model="",                 # checkpoint path, set by VideoFlowCore.load_model
+        network="MOFNetStack",
+        feat_dim=256,             # encoder output channels; hidden = context = feat_dim // 2
+        down_ratio=8,
+        corr_levels=4,
+        corr_radius=4,
+        decoder_depth=12,         # update iterations ("default 12", reference videoflow_core.py:92)
+        # Network input = input_scale * x + input_shift.  The reference hands over x in [0,1]
+        # (processing/videoflow_processor.py:154), (2, -1) maps that onto [-1, 1].  The literal
+        # upstream pair for 0..255 inputs would be (2/255, -1); see DESIGN.md "Input range".
+        input_scale=2.0,
+        input_shift=-1.0,
+    )

@@ -1,0 +1,205 @@
+// Correlation-pyramid lookup (K5), coordinate bookkeeping, 8x convex upsampling (K8).
+// All three are HBM/latency-bound gathers: one wave64 per query (lookup) or per coarse pixel
+// (upsample), patches staged through LDS, results written as contiguous runs.
+#include "vfml_common.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 6;
+constexpr int MAX_RADIUS = 4;
+constexpr int PATCH = 2 * MAX_RADIUS + 2;  // 10 integer-grid samples per axis
+constexpr int LOOKUP_WAVES = 4;
+
+struct LookupArgs {
+  const float* pyr[MAX_LEVELS];
+  int hl[MAX_LEVELS], wl[MAX_LEVELS], ld[MAX_LEVELS];
+  int levels, radius, nq;
+  const float* coords; int ld_coords;
+  float* out; int ld_out;
+};
+
+// One wave per query.  Per level the window's (2r+1)^2 bilinear samples all share the same
+// fractional offset, so they are blends of one (2r+2)^2 integer-grid patch: the wave gathers the
+// patch (zero outside the level) into LDS, then each lane produces output channels
+// o = l*(2r+1)^2 + i*(2r+1) + j  (x + d[i], y + d[j]: RAFT's window order), written contiguously.
+__global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const LookupArgs a) {
+  __shared__ float patch[LOOKUP_WAVES][MAX_LEVELS][PATCH * PATCH];
+  __shared__ float frac[LOOKUP_WAVES][MAX_LEVELS][2];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int q = blockIdx.x * LOOKUP_WAVES + wv;
+  const bool live = q < a.nq;
+  const int side = 2 * a.radius + 2;  // patch side
+  const int win = 2 * a.radius + 1;
+  const int psz = side * side;
+  if (live) {
+    const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
+    const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
+    const int total = a.levels * psz;
+    for (int e = lane; e < total; e += 64) {
+      const int l = e / psz;
+      const int idx = e - l * psz;
+      const int py = idx / side, px = idx - py * side;
+      const float inv = 1.0f / (float)(1 << l);
+      const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
+      const float fx0 = floorf(x), fy0 = floorf(y);
+      // clamp before the int conversion so that wild coordinates cannot overflow
+      const int x0 = (int)fminf(fmaxf(fx0, -65536.f), 65536.f) - a.radius;
+      const int y0 = (int)fminf(fmaxf(fy0, -65536.f), 65536.f) - a.radius;
+      const int xx = x0 + px, yy = y0 + py;
+      float v = 0.f;
+      if (xx >= 0 && xx < a.wl[l] && yy >= 0 && yy < a.hl[l])
+        v = a.pyr[l][(int64_t)q * a.ld[l] + (int64_t)yy * a.wl[l] + xx];
+      patch[wv][l][idx] = v;
+      if (idx == 0) {
+        frac[wv][l][0] = x - fx0;
+        frac[wv][l][1] = y - fy0;
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const int nout = a.levels * win * win;
+  float* o = a.out + (int64_t)q * a.ld_out;
+  for (int c = lane; c < nout; c += 64) {
+    const int l = c / (win * win);
+    const int rem = c - l * win * win;
+    const int i = rem / win, j = rem - i * win;  // i: x offset index, j: y offset index
+    const float fx = frac[wv][l][0], fy = frac[wv][l][1];
+    const float* p = &patch[wv][l][j * side + i];
+    // grid_sample's bilinear: nw*(1-fx)(1-fy) + ne*fx(1-fy) + sw*(1-fx)fy + se*fx*fy
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    o[c] = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[side] * (wx0 * fy) + p[side + 1] * (fx * fy);
+  }
+}
+
+__global__ void coords_init_kernel(f32x4* __restrict__ coords, int h, int w, int64_t total) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % w);
+    const int y = (int)((p / w) % h);
+    f32x4 v = {(float)x, (float)y, (float)x, (float)y};
+    coords[p] = v;
+  }
+}
+
+__global__ void coords_update_kernel(f32x4* __restrict__ coords, const f32x4* __restrict__ delta, int h, int w,
+                                     int64_t total, float* __restrict__ fa, int lda, float* __restrict__ fb, int ldb) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 c = coords[p];
+    if (delta) {
+      c = c + delta[p];
+      coords[p] = c;
+    }
+    const float x = (float)(int)(p % w);
+    const float y = (float)(int)((p / w) % h);
+    const f32x4 f = {c[0] - x, c[1] - y, c[2] - x, c[3] - y};
+    if (fa) *reinterpret_cast<f32x4*>(fa + p * lda) = f;
+    if (fb) *reinterpret_cast<f32x4*>(fb + p * ldb) = f;
+  }
+}
+
+// One wave per coarse pixel, lane = sub-pixel (sy*8+sx).  9 coalesced 256-B mask reads, softmax
+// over the 9 taps in registers, 3x3 coarse flow neighbourhood (zero outside, x8), float2 stores.
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ coords, int ch,
+                                                             const float* __restrict__ mask, int ld_mask, int h,
+                                                             int w, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= h * w) return;
+  const int y = p / w, x = p - y * w;
+  const float* m = mask + (int64_t)p * ld_mask + lane;
+  float logit[9], fxv[9], fyv[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    logit[k] = m[k * 64];
+    mx = fmaxf(mx, logit[k]);
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    float u = 0.f, v = 0.f;
+    if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+      const float* c = coords + ((int64_t)yy * w + xx) * 4 + ch;
+      u = 8.f * (c[0] - (float)xx);
+      v = 8.f * (c[1] - (float)yy);
+    }
+    fxv[k] = u;
+    fyv[k] = v;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    logit[k] = expf(logit[k] - mx);
+    s += logit[k];
+  }
+  float ax = 0.f, ay = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float pk = logit[k] / s;
+    ax += pk * fxv[k];
+    ay += pk * fyv[k];
+  }
+  const int sy = lane >> 3, sx = lane & 7;
+  float2* o = reinterpret_cast<float2*>(out) + ((int64_t)(8 * y + sy) * (8 * w) + 8 * x + sx);
+  *o = make_float2(ax, ay);
+}
+
+inline int grid_for(int64_t items, int block) {
+  int64_t g = (items + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
+                                int levels, int radius, int nq, const float* coords, int ld_coords, float* out,
+                                int ld_out, void* stream) {
+  VFML_REQUIRE(pyr && hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
+  VFML_REQUIRE(levels >= 1 && levels <= MAX_LEVELS, "vfml_corr_lookup: levels=%d out of [1,%d]", levels, MAX_LEVELS);
+  VFML_REQUIRE(radius >= 1 && radius <= MAX_RADIUS, "vfml_corr_lookup: radius=%d out of [1,%d]", radius, MAX_RADIUS);
+  VFML_REQUIRE(nq > 0 && ld_coords >= 2, "vfml_corr_lookup: bad nq/ld_coords");
+  const int nout = levels * (2 * radius + 1) * (2 * radius + 1);
+  VFML_REQUIRE(ld_out >= nout, "vfml_corr_lookup: ld_out=%d < %d channels", ld_out, nout);
+  LookupArgs a;
+  for (int l = 0; l < levels; ++l) {
+    VFML_REQUIRE(pyr[l] && hl[l] > 0 && wl[l] > 0 && ld[l] >= hl[l] * wl[l], "vfml_corr_lookup: bad level %d", l);
+    a.pyr[l] = pyr[l]; a.hl[l] = hl[l]; a.wl[l] = wl[l]; a.ld[l] = ld[l];
+  }
+  for (int l = levels; l < MAX_LEVELS; ++l) { a.pyr[l] = nullptr; a.hl[l] = a.wl[l] = a.ld[l] = 0; }
+  a.levels = levels; a.radius = radius; a.nq = nq;
+  a.coords = coords; a.ld_coords = ld_coords; a.out = out; a.ld_out = ld_out;
+  hipLaunchKernelGGL(corr_lookup_kernel, dim3((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), dim3(64 * LOOKUP_WAVES), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  return vfml_check_launch("vfml_corr_lookup");
+}
+
+extern "C" int vfml_coords_init(float* coords1, int n, int h, int w, void* stream) {
+  VFML_REQUIRE(coords1 && n > 0 && h > 0 && w > 0, "vfml_coords_init: bad argument");
+  VFML_REQUIRE(vfml_aligned16(coords1), "vfml_coords_init: alignment");
+  const int64_t total = (int64_t)n * h * w;
+  hipLaunchKernelGGL(coords_init_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (f32x4*)coords1, h, w, total);
+  return vfml_check_launch("vfml_coords_init");
+}
+
+extern "C" int vfml_coords_update(float* coords1, const float* delta, int n, int h, int w, float* flow_a, int ld_a,
+                                  float* flow_b, int ld_b, void* stream) {
+  VFML_REQUIRE(coords1 && n > 0 && h > 0 && w > 0, "vfml_coords_update: bad argument");
+  VFML_REQUIRE(vfml_aligned16(coords1) && vfml_aligned16(delta) && vfml_aligned16(flow_a) && vfml_aligned16(flow_b),
+               "vfml_coords_update: alignment");
+  VFML_REQUIRE((!flow_a || (ld_a >= 4 && ld_a % 4 == 0)) && (!flow_b || (ld_b >= 4 && ld_b % 4 == 0)),
+               "vfml_coords_update: ld must be a multiple of 4 and >= 4");
+  const int64_t total = (int64_t)n * h * w;
+  hipLaunchKernelGGL(coords_update_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (f32x4*)coords1, (const f32x4*)delta, h, w, total, flow_a,
+                     ld_a, flow_b, ld_b);
+  return vfml_check_launch("vfml_coords_update");
+}
+
+extern "C" int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld_mask, int h, int w,
+                                    float* out, void* stream) {
+  VFML_REQUIRE(coords1 && mask && out, "vfml_convex_upsample: null pointer");
+  VFML_REQUIRE((ch == 0 || ch == 2) && h > 0 && w > 0 && ld_mask >= 576, "vfml_convex_upsample: bad ch/h/w/ld_mask");
+  VFML_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0, "vfml_convex_upsample: out must be 8-byte aligned");
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3((h * w + 3) / 4), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), coords1, ch, mask, ld_mask, h, w, out);
+  return vfml_check_launch("vfml_convex_upsample");
+}

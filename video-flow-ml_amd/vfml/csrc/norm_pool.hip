@@ -1,0 +1,239 @@
+// HBM-bound helper passes: input normalisation (K1), instance-norm statistics / apply (K2),
+// 2x2 average pooling of feature maps (K4 feeder).  All are streaming float4 kernels.
+#include "vfml_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ K1: frames -> NHWC4
+// One thread per pixel: reads 3 B (u8 HWC) or 3 strided floats (f32 CHW), writes one float4.
+__global__ void frames_u8_kernel(const uint8_t* __restrict__ src, int64_t npx, float scale, float shift,
+                                 f32x4* __restrict__ dst) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+    const uint8_t* s = src + p * 3;
+    f32x4 v;
+    // x = u8 / 255 in fp32 first (what the host did in the reference), then the affine map.
+    v[0] = scale * ((float)s[0] / 255.0f) + shift;
+    v[1] = scale * ((float)s[1] / 255.0f) + shift;
+    v[2] = scale * ((float)s[2] / 255.0f) + shift;
+    v[3] = 0.f;
+    dst[p] = v;
+  }
+}
+
+__global__ void frames_f32_kernel(const float* __restrict__ src, int n, int64_t hw, float scale, float shift,
+                                  f32x4* __restrict__ dst) {
+  const int64_t npx = (int64_t)n * hw;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = p / hw, q = p - f * hw;
+    const float* s = src + f * 3 * hw + q;
+    f32x4 v;
+    v[0] = scale * s[0] + shift;
+    v[1] = scale * s[hw] + shift;
+    v[2] = scale * s[2 * hw] + shift;
+    v[3] = 0.f;
+    dst[p] = v;
+  }
+}
+
+// ------------------------------------------------------------------ instance-norm statistics
+// Pass 1: grid (chunks, n).  A block sweeps its pixel chunk; thread = (pixel lane, float4 channel
+// group); sums and sums of squares are carried in double (the CPU reference accumulates in
+// double too), reduced across pixel lanes through LDS, one partial per (chunk, channel).
+// Pass 2: one thread per (n, channel) folds the chunk partials in fixed order -> {mean, rstd}.
+constexpr int STAT_THREADS = 256;
+
+__global__ __launch_bounds__(STAT_THREADS) void instnorm_partial_kernel(const float* __restrict__ x, int hw, int c,
+                                                                      int px_per_chunk, double* __restrict__ part) {
+  const int cg = c >> 2;                  // float4 groups per pixel
+  const int lanes = STAT_THREADS / cg;    // pixel lanes (threads beyond lanes*cg idle)
+  const int t = threadIdx.x;
+  const int g = t % cg;
+  const int pl = t / cg;
+  const int n = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const int p0 = chunk * px_per_chunk;
+  const int p1 = min(hw, p0 + px_per_chunk);
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (pl < lanes) {
+    const f32x4* base = reinterpret_cast<const f32x4*>(x + (int64_t)n * hw * c);
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      const f32x4 v = base[(int64_t)p * cg + g];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = (double)v[e];
+        s[e] += d;
+        q[e] += d * d;
+      }
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sh = reinterpret_cast<double*>(smem_raw);  // [lanes][c][2]
+  if (pl < lanes) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sh[((int64_t)pl * c + g * 4 + e) * 2 + 0] = s[e];
+      sh[((int64_t)pl * c + g * 4 + e) * 2 + 1] = q[e];
+    }
+  }
+  __syncthreads();
+  for (int ch = t; ch < c; ch += STAT_THREADS) {
+    double ss = 0, qq = 0;
+    for (int l = 0; l < lanes; ++l) {
+      ss += sh[((int64_t)l * c + ch) * 2 + 0];
+      qq += sh[((int64_t)l * c + ch) * 2 + 1];
+    }
+    double* o = part + (((int64_t)n * gridDim.x + chunk) * c + ch) * 2;
+    o[0] = ss;
+    o[1] = qq;
+  }
+}
+
+__global__ void instnorm_final_kernel(const double* __restrict__ part, int n, int chunks, int c, int hw, float eps,
+                                      float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const int nn = i / c, ch = i - nn * c;
+  double s = 0, q = 0;
+  for (int k = 0; k < chunks; ++k) {
+    const double* p = part + (((int64_t)nn * chunks + k) * c + ch) * 2;
+    s += p[0];
+    q += p[1];
+  }
+  const double mean = s / hw;
+  double var = q / hw - mean * mean;
+  if (var < 0) var = 0;
+  stats[2 * i + 0] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ------------------------------------------------------------------ instance-norm apply
+template <int MODE>  // 0: relu(norm(x)); 1: relu(res + relu(norm(x))); 2: relu(norm(res) + relu(norm(x)))
+__global__ void instnorm_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ stats,
+                                      const f32x4* __restrict__ res, const float* __restrict__ rstats, int hw, int c,
+                                      int64_t total4, f32x4* __restrict__ out) {
+  const int cg = c >> 2;
+  const int64_t per_n = (int64_t)hw * cg;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_n);
+    const int g = (int)(i % cg);
+    const float* st = stats + ((int64_t)n * c + g * 4) * 2;
+    const f32x4 v = x[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[e] - st[2 * e]) * st[2 * e + 1], 0.f);
+    if (MODE == 1) {
+      const f32x4 rv = res[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(rv[e] + o[e], 0.f);
+    } else if (MODE == 2) {
+      const f32x4 rv = res[i];
+      const float* rs = rstats + ((int64_t)n * c + g * 4) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf((rv[e] - rs[2 * e]) * rs[2 * e + 1] + o[e], 0.f);
+    }
+    out[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ 2x2 average pool (floor)
+__global__ void avgpool2x2_kernel(const f32x4* __restrict__ x, int h, int w, int cg, int ho, int wo, int64_t total4,
+                                  f32x4* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    int64_t p = i / cg;
+    const int ox = (int)(p % wo);
+    p /= wo;
+    const int oy = (int)(p % ho);
+    const int n = (int)(p / ho);
+    const f32x4* b = x + (((int64_t)n * h + 2 * oy) * w + 2 * ox) * cg + g;
+    const f32x4 a0 = b[0], a1 = b[cg], a2 = b[(int64_t)w * cg], a3 = b[(int64_t)w * cg + cg];
+    // same association as at::avg_pool2d's window sum: ((a0 + a1) + a2) + a3, then / 4
+    out[i] = (((a0 + a1) + a2) + a3) * 0.25f;
+  }
+}
+
+inline int grid_for(int64_t items, int block) {
+  int64_t g = (items + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+int stat_chunks(int hw) {
+  int chunks = (hw + 4095) / 4096;
+  return chunks < 1 ? 1 : chunks;
+}
+
+}  // namespace
+
+extern "C" int vfml_frames_to_nhwc4(const void* src, int kind, int n, int H, int W, float scale, float shift,
+                                    float* dst, void* stream) {
+  VFML_REQUIRE(src && dst, "vfml_frames_to_nhwc4: null pointer");
+  VFML_REQUIRE(n > 0 && H > 0 && W > 0, "vfml_frames_to_nhwc4: empty input");
+  VFML_REQUIRE(kind == 0 || kind == 1, "vfml_frames_to_nhwc4: kind must be 0 (u8 HWC) or 1 (f32 CHW)");
+  VFML_REQUIRE(vfml_aligned16(dst), "vfml_frames_to_nhwc4: dst must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t npx = (int64_t)n * H * W;
+  if (kind == 0)
+    hipLaunchKernelGGL(frames_u8_kernel, dim3(grid_for(npx, 256)), dim3(256), 0, s, (const uint8_t*)src, npx, scale,
+                       shift, (f32x4*)dst);
+  else
+    hipLaunchKernelGGL(frames_f32_kernel, dim3(grid_for(npx, 256)), dim3(256), 0, s, (const float*)src, n,
+                       (int64_t)H * W, scale, shift, (f32x4*)dst);
+  return vfml_check_launch("vfml_frames_to_nhwc4");
+}
+
+extern "C" int64_t vfml_instnorm_workspace_bytes(int n, int hw, int c) {
+  return (int64_t)n * stat_chunks(hw) * c * 2 * sizeof(double);
+}
+
+extern "C" int vfml_instnorm_stats(const float* x, int n, int hw, int c, float eps, float* stats, void* workspace,
+                                   void* stream) {
+  VFML_REQUIRE(x && stats && workspace, "vfml_instnorm_stats: null pointer");
+  VFML_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 4 == 0 && c <= 1024, "vfml_instnorm_stats: bad n/hw/c (c%%4==0, c<=1024)");
+  VFML_REQUIRE(vfml_aligned16(x), "vfml_instnorm_stats: x must be 16-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int chunks = stat_chunks(hw);
+  const int px = (hw + chunks - 1) / chunks;
+  const int lanes = STAT_THREADS / (c / 4);
+  VFML_REQUIRE(lanes >= 1, "vfml_instnorm_stats: too many channels");
+  const size_t lds = (size_t)lanes * c * 2 * sizeof(double);
+  VFML_REQUIRE(lds <= 64 * 1024, "vfml_instnorm_stats: LDS budget");
+  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(chunks, n), dim3(STAT_THREADS), lds, s, x, hw, c, px,
+                     (double*)workspace);
+  int rc = vfml_check_launch("vfml_instnorm_stats(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(instnorm_final_kernel, dim3((n * c + 127) / 128), dim3(128), 0, s, (const double*)workspace, n,
+                     chunks, c, hw, eps, stats);
+  return vfml_check_launch("vfml_instnorm_stats(final)");
+}
+
+extern "C" int vfml_instnorm_apply(const float* x, const float* stats, const float* res, const float* res_stats, int n,
+                                   int hw, int c, float* out, void* stream) {
+  VFML_REQUIRE(x && stats && out, "vfml_instnorm_apply: null pointer");
+  VFML_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 4 == 0, "vfml_instnorm_apply: bad n/hw/c");
+  VFML_REQUIRE(!(res_stats && !res), "vfml_instnorm_apply: res_stats without res");
+  VFML_REQUIRE(vfml_aligned16(x) && vfml_aligned16(out) && vfml_aligned16(res), "vfml_instnorm_apply: alignment");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t total4 = (int64_t)n * hw * (c / 4);
+  const dim3 g(grid_for(total4, 256)), b(256);
+  if (!res)
+    hipLaunchKernelGGL(instnorm_apply_kernel<0>, g, b, 0, s, (const f32x4*)x, stats, nullptr, nullptr, hw, c, total4,
+                       (f32x4*)out);
+  else if (!res_stats)
+    hipLaunchKernelGGL(instnorm_apply_kernel<1>, g, b, 0, s, (const f32x4*)x, stats, (const f32x4*)res, nullptr, hw, c,
+                       total4, (f32x4*)out);
+  else
+    hipLaunchKernelGGL(instnorm_apply_kernel<2>, g, b, 0, s, (const f32x4*)x, stats, (const f32x4*)res, res_stats, hw,
+                       c, total4, (f32x4*)out);
+  return vfml_check_launch("vfml_instnorm_apply");
+}
+
+extern "C" int vfml_avgpool2x2(const float* x, int n, int h, int w, int c, float* out, void* stream) {
+  VFML_REQUIRE(x && out, "vfml_avgpool2x2: null pointer");
+  VFML_REQUIRE(n > 0 && h >= 2 && w >= 2 && c > 0 && c % 4 == 0, "vfml_avgpool2x2: bad shape");
+  VFML_REQUIRE(vfml_aligned16(x) && vfml_aligned16(out), "vfml_avgpool2x2: alignment");
+  const int ho = h / 2, wo = w / 2, cg = c / 4;
+  const int64_t total4 = (int64_t)n * ho * wo * cg;
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const f32x4*)x, h, w, cg, ho, wo, total4, (f32x4*)out);
+  return vfml_check_launch("vfml_avgpool2x2");
+}

@@ -1,0 +1,190 @@
+"""ctypes binding of libvfml_hip.so (include/vfml.h).
+
+PyTorch is used for device memory and streams only: every call takes raw device pointers
+(`tensor.data_ptr()`) and launches on torch's current HIP stream.  There is NO CPU fallback:
+if the library is missing or a kernel rejects its arguments this raises.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvfml_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["api.hip", "conv_gemm.hip", "norm_pool.hip", "flow_ops.hip"]
+
+EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q = range(7)
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `vfml_conv_desc` (include/vfml.h)."""
+    _fields_ = [
+        ("in0", c_void_p), ("c0", c_int32), ("ld0", c_int32),
+        ("in1", c_void_p), ("c1", c_int32), ("ld1", c_int32),
+        ("n", c_int32), ("h", c_int32), ("w", c_int32),
+        ("weight", c_void_p), ("bias", c_void_p),
+        ("cout", c_int32), ("kh", c_int32), ("kw", c_int32), ("stride", c_int32),
+        ("pad_h", c_int32), ("pad_w", c_int32),
+        ("out", c_void_p), ("ldo", c_int32),
+        ("epilogue", c_int32), ("split", c_int32), ("out_scale", c_float),
+        ("aux0", c_void_p), ("ld_aux0", c_int32),
+        ("aux1", c_void_p), ("ld_aux1", c_int32),
+    ]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into libvfml_hip.so (in-tree). Cross-compiles without a GPU."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "vfml_common.h"),
+                   os.path.join(_HERE, "..", "..", "include", "vfml.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (after torch, so that its libamdhip64.so.7 is the one HIP runtime in the process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"vfml HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (needs hipcc). There is no CPU fallback for the flow engine.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.vfml_last_error.restype = c_char_p
+    L.vfml_abi_version.restype = c_int
+    L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
+    L.vfml_frames_to_nhwc4.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
+    L.vfml_instnorm_workspace_bytes.restype = c_int64
+    L.vfml_instnorm_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    L.vfml_instnorm_stats.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]
+    L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                   c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]
+    L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+    L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                     c_void_p]
+    L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here = header/library drift
+    if L.vfml_abi_version() != 1:
+        raise RuntimeError("libvfml_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "vfml_conv2d", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
+    "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
+    "vfml_convex_upsample", "vfml_last_error", "vfml_abi_version",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().vfml_last_error().decode()}")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, offset=0):
+    """Device pointer of a float32 tensor's storage start + `offset` floats (0/None-safe)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr() + 4 * offset)
+
+
+def _dev(t, dtype=torch.float32):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"expected a contiguous {dtype} device tensor, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, stride=1, pad_h=0, pad_w=0,
+           in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
+           aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0):
+    """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
+    (channel slices of wider NHWC buffers)."""
+    d = ConvDesc()
+    d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
+    d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
+    d.n, d.h, d.w = n, h, w
+    d.weight, d.bias = _ptr(_dev(weight), weight_off), (_ptr(_dev(bias)) if bias is not None else None)
+    d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w = cout, kh, kw, stride, pad_h, pad_w
+    d.out, d.ldo = _ptr(_dev(out), out_off), ldo
+    d.epilogue, d.split, d.out_scale = epilogue, split, out_scale
+    d.aux0, d.ld_aux0 = (_ptr(_dev(aux0), aux0_off) if aux0 is not None else None), ld_aux0
+    d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
+    _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
+
+
+def frames_to_nhwc4(src, n, H, W, scale, shift, dst):
+    """src: uint8 [n,H,W,3] or float32 [n,3,H,W] device tensor -> dst float32 [n,H,W,4]."""
+    if src.dtype == torch.uint8:
+        kind = 0
+    elif src.dtype == torch.float32:
+        kind = 1
+    else:
+        raise ValueError(f"frames must be uint8 HWC or float32 CHW, got {src.dtype}")
+    if not (src.is_cuda and src.is_contiguous()):
+        raise ValueError("frames must be a contiguous device tensor")
+    _check(lib().vfml_frames_to_nhwc4(c_void_p(src.data_ptr()), kind, n, H, W, scale, shift, _ptr(_dev(dst)),
+                                      _stream()), "vfml_frames_to_nhwc4")
+
+
+def instnorm_workspace_bytes(n, hw, c):
+    return int(lib().vfml_instnorm_workspace_bytes(n, hw, c))
+
+
+def instnorm_stats(x, n, hw, c, stats, workspace, eps=1e-5):
+    _check(lib().vfml_instnorm_stats(_ptr(_dev(x)), n, hw, c, eps, _ptr(_dev(stats)),
+                                     c_void_p(workspace.data_ptr()), _stream()), "vfml_instnorm_stats")
+
+
+def instnorm_apply(x, stats, n, hw, c, out, res=None, res_stats=None):
+    _check(lib().vfml_instnorm_apply(_ptr(_dev(x)), _ptr(_dev(stats)), _ptr(res), _ptr(res_stats), n, hw, c,
+                                     _ptr(_dev(out)), _stream()), "vfml_instnorm_apply")
+
+
+def avgpool2x2(x, n, h, w, c, out):
+    _check(lib().vfml_avgpool2x2(_ptr(_dev(x)), n, h, w, c, _ptr(_dev(out)), _stream()), "vfml_avgpool2x2")
+
+
+def corr_lookup(pyr, hl, wl, ld, radius, nq, coords, coords_off, ld_coords, out, out_off, ld_out, row_off=0):
+    """pyr: list of flat float32 device tensors (one per level); row_off: first query row inside each level."""
+    L = len(pyr)
+    ptrs = (c_void_p * L)(*[p.data_ptr() + 4 * row_off * ld[i] for i, p in enumerate(pyr)])
+    _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius, nq,
+                                  _ptr(_dev(coords), coords_off), ld_coords, _ptr(_dev(out), out_off), ld_out,
+                                  _stream()), "vfml_corr_lookup")
+
+
+def coords_init(coords1, n, h, w):
+    _check(lib().vfml_coords_init(_ptr(_dev(coords1)), n, h, w, _stream()), "vfml_coords_init")
+
+
+def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None, ld_b=0, flow_b_off=0):
+    _check(lib().vfml_coords_update(_ptr(_dev(coords1)), _ptr(delta), n, h, w,
+                                    _ptr(flow_a, flow_a_off), ld_a, _ptr(flow_b, flow_b_off), ld_b, _stream()),
+           "vfml_coords_update")
+
+
+def convex_upsample(coords1, coords_off, ch, mask, mask_off, ld_mask, h, w, out, out_off=0):
+    _check(lib().vfml_convex_upsample(_ptr(_dev(coords1), coords_off), ch, _ptr(_dev(mask), mask_off), ld_mask, h, w,
+                                      _ptr(_dev(out), out_off), _stream()), "vfml_convex_upsample")

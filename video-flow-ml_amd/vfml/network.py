@@ -1,0 +1,287 @@
+"""MOFNetHIP — the multi-frame optical-flow network executed by the vfml HIP kernels.
+
+`build_network(cfg)` stands in for `core.Networks.build_network` of the VideoFlow submodule
+(reference processing/videoflow_core.py:28,101).  The returned module honours the call the
+reference makes at :188, `model(images[B,N,3,H,W], {}) -> (flow[B,2(N-2),2,H,W], aux)`, with the
+forward flows of the N-2 centre frames first and the backward flows after them, so that the
+reference's `flow[0, shape[1]//2]` pick (:194-195) lands on the same field.
+
+Python only sequences kernels; all arithmetic runs in libvfml_hip.so (include/vfml.h) on NHWC
+fp32 buffers.  There is no CPU execution path in this module: on a non-GPU device `forward`
+raises.
+
+Pipeline per call (names from SURVEY.md §2b):
+  K1 frames -> NHWC4, normalised           vfml_frames_to_nhwc4
+  K2 fnet (N frames) / cnet (N-2 frames)   vfml_conv2d + vfml_instnorm_{stats,apply}
+  K3/K4 correlation pyramid, 2(N-2) problems: level l = GEMM of centre features against the
+        2^l-pooled target features (avg-pool commutes with the dot product)   vfml_avgpool2x2, vfml_conv2d
+  loop decoder_depth times:
+     K5 lookup (fwd, bwd)                  vfml_corr_lookup
+     K6 motion encoder, temporal fusion, SepConvGRU (gates fused into the conv epilogues),
+        flow head                          vfml_conv2d, vfml_coords_update
+  mask head (last iteration only) + K8 8x convex upsampling   vfml_conv2d, vfml_convex_upsample
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .weights import conv_spec, pack_conv_weight
+
+
+class _Holder(nn.Module):
+    """Parameter container; children are created on demand so that dotted checkpoint keys
+    (`fnet.layer2.0.downsample.0.weight`) map onto a module tree for load_state_dict."""
+
+    def child(self, name):
+        if name not in self._modules:
+            self.add_module(name, _Holder())
+        return self._modules[name]
+
+
+class MOFNetHIP(_Holder):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.hidden_dim = self.context_dim = cfg.feat_dim // 2
+        if cfg.feat_dim != 256:
+            raise ValueError("MOFNetHIP is built for feat_dim=256")
+        self._spec = conv_spec(cfg)
+        for name, cout, cin, kh, kw in self._spec:
+            leaf = self
+            for p in name.split("."):
+                leaf = leaf.child(p)
+            leaf.weight = nn.Parameter(torch.zeros(cout, cin, kh, kw), requires_grad=False)
+            leaf.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+
+    # ------------------------------------------------------------------ weights
+    def _param(self, name):
+        node = self
+        for p in name.split("."):
+            node = node._modules[p]
+        return node
+
+    def _pack(self, device):
+        """Repack every conv weight into the kernels' [cout][kh][kw][cin] order (once per load)."""
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        P = {}
+        for name, cout, cin, kh, kw in self._spec:
+            leaf = self._param(name)
+            w = leaf.weight.detach().to(device=device, dtype=torch.float32)
+            if name.endswith(".tprop"):
+                # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
+                w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
+            P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None),
+                       leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous())
+        # z and r gates share their input: one conv with 2*hidden outputs per GRU pass
+        for k in ("1", "2"):
+            wz, bz = P[f"update_block.gru.convz{k}"]
+            wr, br = P[f"update_block.gru.convr{k}"]
+            P[f"update_block.gru.convzr{k}"] = (torch.cat([wz, wr]).contiguous(), torch.cat([bz, br]).contiguous())
+        self._packed, self._packed_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ workspace
+    def _buf(self, name, numel, device, dtype=torch.float32):
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.device != device or t.dtype != dtype:
+            t = torch.empty(int(numel), device=device, dtype=dtype)
+            self._ws[name] = t
+        return t
+
+    def release_workspace(self):
+        self._ws.clear()
+
+    # ------------------------------------------------------------------ encoder
+    def _encoder(self, prefix, x, n, H, W, P, dev, out, ldo, out_off, epilogue, split):
+        """RAFT BasicEncoder on NHWC4 input x [n,H,W,4]; writes [n,H/8,W/8,256] into `out`."""
+        h2, w2 = H // 2, W // 2
+        big = n * h2 * w2 * 64
+        raw = self._buf("enc_raw", big, dev)
+        raw2 = self._buf("enc_raw2", big, dev)
+        act = [self._buf("enc_act0", big, dev), self._buf("enc_act1", big, dev), self._buf("enc_act2", big, dev)]
+        st = self._buf("enc_stats", 3 * n * 128 * 2, dev)
+        nws = hip.instnorm_workspace_bytes(n, h2 * w2, 128)
+        ws = self._buf("enc_statws", (nws + 7) // 8, dev, torch.float64)
+
+        def stats_of(t, hw, c, slot):
+            s = st[slot * n * 128 * 2:]
+            hip.instnorm_stats(t, n, hw, c, s, ws)
+            return s
+
+        wgt, b = P[f"{prefix}.conv1"]
+        hip.conv2d(x, 4, 4, n, H, W, wgt, b, 64, 7, 7, raw, 64, stride=2, pad_h=3, pad_w=3)
+        s0 = stats_of(raw, h2 * w2, 64, 0)
+        cur = act[0]
+        hip.instnorm_apply(raw, s0, n, h2 * w2, 64, cur)
+        ch, hh, ww, ci = 64, h2, w2, 0
+        for li, (planes, stride) in enumerate([(64, 1), (96, 2), (128, 2)], start=1):
+            for bi in range(2):
+                stv = stride if bi == 0 else 1
+                ho, wo = (hh, ww) if stv == 1 else ((hh - 1) // 2 + 1, (ww - 1) // 2 + 1)
+                name = f"{prefix}.layer{li}.{bi}"
+                y = act[(ci + 1) % 3]
+                nxt = act[(ci + 2) % 3]
+                wgt, b = P[f"{name}.conv1"]
+                hip.conv2d(cur, ch, ch, n, hh, ww, wgt, b, planes, 3, 3, raw, planes, stride=stv, pad_h=1, pad_w=1)
+                s1 = stats_of(raw, ho * wo, planes, 0)
+                hip.instnorm_apply(raw, s1, n, ho * wo, planes, y)
+                wgt, b = P[f"{name}.conv2"]
+                hip.conv2d(y, planes, planes, n, ho, wo, wgt, b, planes, 3, 3, raw, planes, pad_h=1, pad_w=1)
+                s2 = stats_of(raw, ho * wo, planes, 1)
+                if stv != 1:
+                    wgt, b = P[f"{name}.downsample.0"]
+                    hip.conv2d(cur, ch, ch, n, hh, ww, wgt, b, planes, 1, 1, raw2, planes, stride=stv)
+                    s3 = stats_of(raw2, ho * wo, planes, 2)
+                    hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=raw2, res_stats=s3)
+                else:
+                    hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=cur)
+                cur, ci = nxt, (ci + 2) % 3
+                ch, hh, ww = planes, ho, wo
+        wgt, b = P[f"{prefix}.conv2"]
+        hip.conv2d(cur, 128, 128, n, hh, ww, wgt, b, 256, 1, 1, out, ldo, out_off=out_off, epilogue=epilogue,
+                   split=split)
+        return hh, ww
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, images, data=None, return_lowres=True):
+        cfg = self.cfg
+        if not images.is_cuda:
+            raise RuntimeError("MOFNetHIP runs on an MI355X (HIP) device only; got a tensor on "
+                               f"{images.device}. There is no CPU fallback in the shipped engine.")
+        if images.dim() != 5 or images.shape[2] != 3:
+            raise ValueError(f"images must be [B,N,3,H,W], got {tuple(images.shape)}")
+        B, N, _, H, W = images.shape
+        if B != 1:
+            raise ValueError(f"Batch size must be 1, got {B}")
+        if N < 3:
+            raise ValueError(f"need at least 3 frames, got {N}")
+        if H % 8 or W % 8:
+            raise ValueError("H and W must be multiples of 8 (use InputPadder)")
+        L, R, D = cfg.corr_levels, cfg.corr_radius, cfg.feat_dim
+        h, w = H // 8, W // 8
+        if (h >> (L - 1)) < 2 or (w >> (L - 1)) < 2:
+            raise ValueError(f"frame {H}x{W} too small for a {L}-level correlation pyramid")
+        dev = images.device
+        M = N - 2
+        Pn = h * w          # cells per map
+        MP = M * Pn
+        P = self._pack(dev)
+        win = (2 * R + 1) ** 2
+        cor = L * win
+
+        with torch.cuda.device(dev):
+            # K1
+            frames = self._buf("frames", N * H * W * 4, dev)
+            src = images[0]
+            if src.dtype not in (torch.uint8, torch.float32):
+                src = src.float()
+            hip.frames_to_nhwc4(src.contiguous(), N, H, W, float(cfg.input_scale), float(cfg.input_shift), frames)
+
+            # K2 feature encoder on all N frames
+            fmap = self._buf("fmap", N * Pn * D, dev)
+            self._encoder("fnet", frames, N, H, W, P, dev, fmap, D, 0, hip.EPI_NONE, 0)
+
+            # target-feature pyramid (levels 1..L-1), all frames
+            hl, wl = [h], [w]
+            fl = [fmap]
+            for l in range(1, L):
+                hl.append(hl[-1] // 2)
+                wl.append(wl[-1] // 2)
+                t = self._buf(f"fmap_l{l}", N * hl[l] * wl[l] * D, dev)
+                hip.avgpool2x2(fl[-1], N, hl[l - 1], wl[l - 1], D, t)
+                fl.append(t)
+            Sl = [hl[l] * wl[l] for l in range(L)]
+            ldl = [(s + 31) // 32 * 32 for s in Sl]
+
+            # K3/K4 correlation pyramids: rows = (centre frame, query cell)
+            pyr = {d: [self._buf(f"pyr_{d}{l}", MP * ldl[l], dev) for l in range(L)] for d in ("f", "b")}
+            scale = 1.0 / float(D) ** 0.5
+            for c in range(1, N - 1):
+                for d, tgt in (("f", c + 1), ("b", c - 1)):
+                    for l in range(L):
+                        hip.conv2d(fmap, D, D, 1, 1, Pn, fl[l], None, Sl[l], 1, 1, pyr[d][l], ldl[l],
+                                   in0_off=c * Pn * D, out_off=(c - 1) * Pn * ldl[l], out_scale=scale,
+                                   weight_off=tgt * Sl[l] * D)
+
+            # K2 context encoder on the centre frames -> hx[:, 0:128] = tanh, hx[:, 128:256] = relu
+            hx = self._buf("hx", MP * 512, dev)
+            self._encoder("cnet", frames[H * W * 4:], M, H, W, P, dev, hx, 512, 0, hip.EPI_TANH_RELU, self.hidden_dim)
+
+            corr = self._buf("corr", MP * 2 * cor, dev)
+            c1 = self._buf("c1", MP * 256, dev)
+            cf = self._buf("cf", MP * 256, dev)
+            f1 = self._buf("f1", MP * 128, dev)
+            zr = self._buf("zr", MP * 256, dev)
+            fh = self._buf("fh", MP * 256, dev)
+            flow4 = self._buf("flow4", MP * 4, dev)
+            delta = self._buf("delta", MP * 4, dev)
+            coords1 = self._buf("coords1", MP * 4, dev)
+
+            hip.coords_init(coords1, M, h, w)
+            hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=hx, ld_b=512, flow_b_off=380)
+            ub = "update_block"
+            for it in range(cfg.decoder_depth):
+                # K5
+                hip.corr_lookup(pyr["f"], hl, wl, ldl, R, MP, coords1, 0, 4, corr, 0, 2 * cor)
+                hip.corr_lookup(pyr["b"], hl, wl, ldl, R, MP, coords1, 2, 4, corr, cor, 2 * cor)
+                # motion encoder
+                wgt, b = P[f"{ub}.encoder.convc1"]
+                hip.conv2d(corr, 2 * cor, 2 * cor, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU)
+                wgt, b = P[f"{ub}.encoder.convc2"]
+                hip.conv2d(c1, 256, 256, M, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
+                wgt, b = P[f"{ub}.encoder.convf1"]
+                hip.conv2d(flow4, 4, 4, M, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU)
+                wgt, b = P[f"{ub}.encoder.convf2"]
+                hip.conv2d(f1, 128, 128, M, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU)
+                wgt, b = P[f"{ub}.encoder.conv"]
+                hip.conv2d(cf, 256, 256, M, h, w, wgt, b, 124, 3, 3, hx, 512, out_off=256, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU)
+                # temporal stack fusion: 3x1 conv along the frame axis of the motion features
+                wgt, b = P[f"{ub}.tprop"]
+                hip.conv2d(hx, 128, 512, 1, M, Pn, wgt, b, 128, 3, 1, hx, 512, in0_off=256, out_off=384, pad_h=1,
+                           epilogue=hip.EPI_RELU)
+                # SepConvGRU, horizontal then vertical
+                for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+                    wgt, b = P[f"{ub}.gru.convzr{k}"]
+                    hip.conv2d(hx, 512, 512, M, h, w, wgt, b, 256, kh, kw, zr, 256, pad_h=kh // 2, pad_w=kw // 2,
+                               epilogue=hip.EPI_GRU_ZR, split=128, aux0=hx, ld_aux0=512)
+                    wgt, b = P[f"{ub}.gru.convq{k}"]
+                    hip.conv2d(zr, 128, 256, M, h, w, wgt, b, 128, kh, kw, hx, 512, in0_off=128,
+                               in1=hx, c1=384, ld1=512, in1_off=128, pad_h=kh // 2, pad_w=kw // 2,
+                               epilogue=hip.EPI_GRU_Q, aux0=zr, ld_aux0=256, aux1=hx, ld_aux1=512)
+                # flow head
+                wgt, b = P[f"{ub}.flow_head.conv1"]
+                hip.conv2d(hx, 128, 512, M, h, w, wgt, b, 256, 3, 3, fh, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
+                wgt, b = P[f"{ub}.flow_head.conv2"]
+                hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1)
+                hip.coords_update(coords1, delta, M, h, w, flow_a=flow4, ld_a=4, flow_b=hx, ld_b=512, flow_b_off=380)
+
+            # mask head on the final hidden state, then K8 for every flow of the output tensor
+            mask = self._buf("mask", MP * 1152, dev)
+            wgt, b = P[f"{ub}.mask.0"]
+            hip.conv2d(hx, 128, 512, M, h, w, wgt, b, 256, 3, 3, fh, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
+            wgt, b = P[f"{ub}.mask.2"]
+            hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25)
+            up = torch.empty(2 * M, H, W, 2, device=dev, dtype=torch.float32)
+            upf = up.view(-1)
+            for d in range(2):
+                for c in range(M):
+                    hip.convex_upsample(coords1, c * Pn * 4, 2 * d, mask, c * Pn * 1152 + d * 576, 1152, h, w, upf,
+                                        out_off=(d * M + c) * H * W * 2)
+            # [2M,H,W,2] stored HWC; expose the reference's [B, 2M, 2, H, W] as a view
+            flow = up.permute(0, 3, 1, 2).unsqueeze(0)
+            low = None
+            if return_lowres:
+                low = flow4.view(M, h, w, 4)[..., :].clone()
+        return flow, low
+
+
+def build_network(cfg):
+    return MOFNetHIP(cfg)
