@@ -72,6 +72,14 @@ class MOFNetHIP(_Holder):
         for name, cout, cin, kh, kw in self._spec:
             leaf = self._param(name)
             w = leaf.weight.detach().to(device=device, dtype=torch.float32)
+            if name.endswith(".encoder.convc1"):
+                # each direction's lookup block is padded to a multiple of 4 channels (zero weights)
+                cor = cin // 2
+                cor_p = (cor + 3) // 4 * 4
+                wp = torch.zeros(cout, 2 * cor_p, 1, 1, device=device)
+                wp[:, :cor] = w[:, :cor]
+                wp[:, cor_p:cor_p + cor] = w[:, cor:]
+                w = wp
             if name.endswith(".tprop"):
                 # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
                 w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
@@ -86,10 +94,11 @@ class MOFNetHIP(_Holder):
         return P
 
     # ------------------------------------------------------------------ workspace
-    def _buf(self, name, numel, device, dtype=torch.float32):
+    def _buf(self, name, numel, device, dtype=torch.float32, zero=False):
+        """Named scratch buffer, cached per exact size (a resolution change reallocates)."""
         t = self._ws.get(name)
-        if t is None or t.numel() < numel or t.device != device or t.dtype != dtype:
-            t = torch.empty(int(numel), device=device, dtype=dtype)
+        if t is None or t.numel() != numel or t.device != device or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(int(numel), device=device, dtype=dtype)
             self._ws[name] = t
         return t
 
@@ -150,15 +159,31 @@ class MOFNetHIP(_Holder):
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, images, data=None, return_lowres=True):
-        cfg = self.cfg
-        if not images.is_cuda:
-            raise RuntimeError("MOFNetHIP runs on an MI355X (HIP) device only; got a tensor on "
-                               f"{images.device}. There is no CPU fallback in the shipped engine.")
+        """images: float [B=1, N, 3, H, W] on the GPU (the tensor the reference builds at
+        processing/videoflow_processor.py:160-161). Returns (flow [1, 2(N-2), 2, H, W], low-res flows)."""
+        if not isinstance(images, torch.Tensor) or not images.is_cuda:
+            raise RuntimeError("MOFNetHIP runs on an MI355X (HIP) device only; got "
+                               f"{getattr(images, 'device', type(images))}. There is no CPU fallback in the shipped engine.")
         if images.dim() != 5 or images.shape[2] != 3:
             raise ValueError(f"images must be [B,N,3,H,W], got {tuple(images.shape)}")
-        B, N, _, H, W = images.shape
-        if B != 1:
-            raise ValueError(f"Batch size must be 1, got {B}")
+        if images.shape[0] != 1:
+            raise ValueError(f"Batch size must be 1, got {images.shape[0]}")
+        src = images[0]
+        if src.dtype != torch.float32:
+            src = src.float()
+        return self._run(src.contiguous(), src.shape[0], src.shape[2], src.shape[3], return_lowres)
+
+    @torch.no_grad()
+    def forward_u8(self, frames, return_lowres=True):
+        """frames: uint8 [N, H, W, 3] RGB on the GPU; /255 happens in the K1 kernel (same fp32 ops
+        as the reference's host-side conversion), saving the 4x larger float upload."""
+        if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8
+                and frames.dim() == 4 and frames.shape[3] == 3):
+            raise ValueError("forward_u8 expects a uint8 [N,H,W,3] device tensor")
+        return self._run(frames.contiguous(), frames.shape[0], frames.shape[1], frames.shape[2], return_lowres)
+
+    def _run(self, src, N, H, W, return_lowres):
+        cfg = self.cfg
         if N < 3:
             raise ValueError(f"need at least 3 frames, got {N}")
         if H % 8 or W % 8:
@@ -167,21 +192,19 @@ class MOFNetHIP(_Holder):
         h, w = H // 8, W // 8
         if (h >> (L - 1)) < 2 or (w >> (L - 1)) < 2:
             raise ValueError(f"frame {H}x{W} too small for a {L}-level correlation pyramid")
-        dev = images.device
+        dev = src.device
         M = N - 2
         Pn = h * w          # cells per map
         MP = M * Pn
         P = self._pack(dev)
         win = (2 * R + 1) ** 2
         cor = L * win
+        cor_p = (cor + 3) // 4 * 4   # per-direction channel block, 16-byte aligned
 
         with torch.cuda.device(dev):
             # K1
             frames = self._buf("frames", N * H * W * 4, dev)
-            src = images[0]
-            if src.dtype not in (torch.uint8, torch.float32):
-                src = src.float()
-            hip.frames_to_nhwc4(src.contiguous(), N, H, W, float(cfg.input_scale), float(cfg.input_shift), frames)
+            hip.frames_to_nhwc4(src, N, H, W, float(cfg.input_scale), float(cfg.input_shift), frames)
 
             # K2 feature encoder on all N frames
             fmap = self._buf("fmap", N * Pn * D, dev)
@@ -213,7 +236,7 @@ class MOFNetHIP(_Holder):
             hx = self._buf("hx", MP * 512, dev)
             self._encoder("cnet", frames[H * W * 4:], M, H, W, P, dev, hx, 512, 0, hip.EPI_TANH_RELU, self.hidden_dim)
 
-            corr = self._buf("corr", MP * 2 * cor, dev)
+            corr = self._buf("corr", MP * 2 * cor_p, dev, zero=True)   # pad channels stay zero
             c1 = self._buf("c1", MP * 256, dev)
             cf = self._buf("cf", MP * 256, dev)
             f1 = self._buf("f1", MP * 128, dev)
@@ -228,11 +251,11 @@ class MOFNetHIP(_Holder):
             ub = "update_block"
             for it in range(cfg.decoder_depth):
                 # K5
-                hip.corr_lookup(pyr["f"], hl, wl, ldl, R, MP, coords1, 0, 4, corr, 0, 2 * cor)
-                hip.corr_lookup(pyr["b"], hl, wl, ldl, R, MP, coords1, 2, 4, corr, cor, 2 * cor)
+                hip.corr_lookup(pyr["f"], hl, wl, ldl, R, MP, coords1, 0, 4, corr, 0, 2 * cor_p)
+                hip.corr_lookup(pyr["b"], hl, wl, ldl, R, MP, coords1, 2, 4, corr, cor_p, 2 * cor_p)
                 # motion encoder
                 wgt, b = P[f"{ub}.encoder.convc1"]
-                hip.conv2d(corr, 2 * cor, 2 * cor, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU)
+                hip.conv2d(corr, 2 * cor_p, 2 * cor_p, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU)
                 wgt, b = P[f"{ub}.encoder.convc2"]
                 hip.conv2d(c1, 256, 256, M, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
                 wgt, b = P[f"{ub}.encoder.convf1"]
