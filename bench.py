@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — flow-fields/sec of the MI355X engine on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one flow field: MOF_sintel, seq_len=5, 1920x1080, synthetic clip (BASELINE.json configs[1]),
+computed through the drop-in API (processing.VideoFlowProcessor -> VideoFlowCore -> HIP engine) from a
+uint8 clip already resident in HBM, result left in HBM as [H,W,2] float32.  With N>1 every rank
+runs K steps on its own frame range (weak scaling, no data-path collective) and one RCCL gather
+brings the finished fields to rank 0 inside the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel (the f32-MFMA implicit-GEMM conv/GEMM), achieved TFLOP/s from HIP
+                events recorded around its launches inside the timed region, vs the f32 matrix peak
+  cpu_baseline  the CPU oracle (oracle/mof_oracle.py, "port") timed on this box's host cores on a
+                bounded sample of the same workload (N=1 only), plus the engine-vs-oracle EPE on it
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--seq", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-height", type=int, default=0,
+                    help="CPU-baseline sample: full frame if 0, else a centre crop of this height (16:9)")
+    args = ap.parse_args()
+
+    from vfml import dist as vdist, get_cfg, hip
+    from vfml.synth import synthetic_clip
+    from vfml.weights import write_seeded_checkpoint
+
+    rank, local_rank, world = vdist.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    hip.lib()  # fail loudly if the HIP extension is missing
+
+    # -- model through the reference's API path ------------------------------------------------
+    work = tempfile.mkdtemp(prefix=f"vfml_bench_r{rank}_")
+    write_seeded_checkpoint(work, get_cfg(), seed=0)
+    os.chdir(work)
+    import contextlib
+    import io
+    from config import DeviceManager
+    from processing.videoflow_processor import VideoFlowProcessor
+    with contextlib.redirect_stdout(io.StringIO()):
+        device_name = DeviceManager().get_device("cuda")
+        proc = VideoFlowProcessor(device_name if world == 1 else f"cuda:{local_rank}", sequence_length=args.seq)
+        proc.load_model()
+
+    # -- synthetic clip, uploaded once ---------------------------------------------------------
+    K, Wm, T = args.steps, args.warmup, args.seq
+    per_rank = K + Wm
+    nframes = per_rank + T - 1
+    # every rank generates the same clip and works on its own window range (frame-range sharding
+    # with a T//2 halo; here the "global" clip is world * per_rank fields long)
+    clip_np = synthetic_clip(world * per_rank + T - 1, args.height, args.width)
+    lo = rank * per_rank
+    clip = proc.upload_clip(clip_np[lo:lo + nframes])
+    half = T // 2
+    fields = [half + i for i in range(per_rank)]          # local indices with a full window
+    torch.cuda.synchronize()
+
+    for i in fields[:Wm]:
+        proc.compute_optical_flow_resident(clip, i)
+    torch.cuda.synchronize()
+    vdist.barrier(dev)
+
+    out = torch.empty(K, args.height, args.width, 2, device=dev)
+    hip.profile_begin()
+    t0 = time.perf_counter()
+    for k, i in enumerate(fields[Wm:]):
+        out[k].copy_(proc.compute_optical_flow_resident(clip, i))
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0
+    tg = time.perf_counter()
+    gathered = vdist.gather_to_rank0(out.view(-1), [out.numel()] * world)
+    torch.cuda.synchronize()
+    t_gather = time.perf_counter() - tg
+    vdist.barrier(dev)
+    elapsed = time.perf_counter() - t0
+    prof = hip.profile_end()
+    elapsed = vdist.max_over_ranks(elapsed, dev)
+    if rank != 0:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
+    assert gathered is not None and len(gathered) == world
+
+    total_fields = K * world
+    result = {
+        "metric": "flow-fields/sec @1080p seq5 MOF_sintel",
+        "value": total_fields / elapsed,
+        "unit": "flow-fields/s",
+        "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": 1000.0 * elapsed / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"MOF_sintel seq_len={T} {args.width}x{args.height} synthetic clip, "
+                               f"decoder_depth={proc.core.cfg.decoder_depth}, seeded weights",
+                   "fields_per_gpu": K, "clip_frames_per_gpu": nframes, "parallelism": f"frames-dp{world}",
+                   "inputs": "uint8 clip resident in HBM", "outputs": "[H,W,2] f32 in HBM, gathered to rank 0"},
+        "compute_ms_per_step": 1000.0 * t_compute / K,
+        "gather_ms": 1000.0 * t_gather,
+    }
+
+    # -- roofline of the dominant kernel -------------------------------------------------------
+    if prof:
+        name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": name, "bound": "mfma", "achieved": achieved, "peak": F32_MATRIX_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "launches": d["launches"], "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
+            "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+            "share_of_step": d["ms"] / (1000.0 * t_compute),
+            "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                 "launches": v["launches"]} for k, v in prof.items()},
+        }
+
+    # -- CPU baseline (oracle) on a bounded sample of the same workload -------------------------
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, proc, clip_np, fields[Wm], out[0], T)
+    print(json.dumps(result))
+
+
+def cpu_baseline(args, proc, clip_np, field_idx, engine_field, T):
+    """One flow field of the workload on the host cores with the CPU oracle; also the EPE between
+    that field and the engine's (the same window, the same seeded weights)."""
+    from oracle import mof_oracle as mo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = mo.get_cfg()
+    ocfg.decoder_depth = proc.core.cfg.decoder_depth
+    ora = mo.build_network(ocfg).eval()
+    ora.load_state_dict({k: v.cpu() for k, v in proc.core.model.state_dict().items()})
+    idx = proc.window_indices(len(clip_np), field_idx)
+    win = np.stack([clip_np[i] for i in idx])
+    H, W = win.shape[1:3]
+    y0 = x0 = 0
+    if args.cpu_sample_height and args.cpu_sample_height < H:
+        h = args.cpu_sample_height // 8 * 8
+        w = min(W, (h * 16 // 9) // 8 * 8)
+        y0, x0 = (H - h) // 2 // 8 * 8, (W - w) // 2 // 8 * 8
+        win = win[:, y0:y0 + h, x0:x0 + w]
+    x = torch.from_numpy(win.astype(np.float32) / 255.0).permute(0, 3, 1, 2)[None]
+    t0 = time.perf_counter()
+    flows, _ = ora(x, {})
+    dt = time.perf_counter() - t0
+    ref = flows[0, flows.shape[1] // 2].permute(1, 2, 0)
+    full = win.shape[1] == H and win.shape[2] == W
+    out = {"value": 1.0 / dt, "unit": "flow-fields/s", "cores": cores, "kind": "port",
+           "seconds": dt, "threads": torch.get_num_threads()}
+    if full:
+        epe = (engine_field.cpu() - ref).pow(2).sum(-1).sqrt()
+        out["sample"] = f"1 full {W}x{H} seq{T} field (field {field_idx} of the clip), fp32 PyTorch CPU oracle"
+        out["epe_mean_px"] = float(epe.mean())
+        out["epe_max_px"] = float(epe.max())
+    else:
+        out["sample"] = (f"1 field on a {win.shape[2]}x{win.shape[1]} centre crop of the {W}x{H} clip; "
+                         f"value is per cropped field (NOT area-scaled: correlation cost is quadratic in area)")
+    return out
+
+
+if __name__ == "__main__":
+    main()

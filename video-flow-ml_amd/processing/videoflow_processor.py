@@ -1,0 +1,193 @@
+"""VideoFlowProcessor — frame windows, tiles and numpy<->tensor plumbing around VideoFlowCore.
+
+API mirror of reference processing/videoflow_processor.py:20-361.  Behaviour kept bit-for-bit:
+window selection and padding asymmetry (:133-147), u8 -> float32 /255 and HWC->CHW (:150-161),
+fixed 1280x1280 row-major tiles with ragged edge tiles and hard seams (:73-110, :231-283),
+[H,W,2] float32 numpy output (:185).
+"""
+import numpy as np
+import torch
+
+from .videoflow_core import VideoFlowCore
+
+
+class VideoFlowProcessor:
+    def __init__(self, device, fast_mode=False, tile_mode=False, sequence_length=5,
+                 dataset='sintel', architecture='mof', variant='standard'):
+        self.device = device
+        self.fast_mode = fast_mode
+        self.tile_mode = tile_mode
+        self.sequence_length = sequence_length
+        self.dataset = dataset
+        self.architecture = architecture
+        self.variant = variant
+        self.core = VideoFlowCore(device, fast_mode, dataset, architecture, variant)
+        print("VideoFlow Processor initialized:")
+        for label, value in (("Device", device), ("Fast mode", fast_mode), ("Tile mode", tile_mode),
+                             ("Sequence length", sequence_length), ("Dataset", dataset),
+                             ("Architecture", architecture.upper()), ("Variant", variant)):
+            print(f"  {label}: {value}")
+
+    def load_model(self):
+        print(f"VideoFlow model loaded successfully from: {self.core.load_model()}")
+
+    # -- tiles ------------------------------------------------------------------------------
+    def calculate_tile_grid(self, width, height, tile_size=1280):
+        """-> (tile_width, tile_height, cols, rows, tiles_info); tiles row-major, edge tiles clipped."""
+        cols = -(-width // tile_size)
+        rows = -(-height // tile_size)
+        tiles = [{'x': c * tile_size, 'y': r * tile_size,
+                  'width': min(tile_size, width - c * tile_size),
+                  'height': min(tile_size, height - r * tile_size),
+                  'col': c, 'row': r}
+                 for r in range(rows) for c in range(cols)]
+        return tile_size, tile_size, cols, rows, tiles
+
+    def extract_tile(self, frame, tile_info):
+        x, y = tile_info['x'], tile_info['y']
+        return frame[y:y + tile_info['height'], x:x + tile_info['width']]
+
+    # -- windows ----------------------------------------------------------------------------
+    def window_indices(self, num_frames, frame_idx):
+        """Frame indices of the T-frame window the reference builds for `frame_idx` (:133-147):
+        centred, clipped to the clip, then padded to T by repeating the first frame at the front when
+        the window starts at frame 0, else the last frame at the back."""
+        T = self.sequence_length
+        half = T // 2
+        start = max(0, frame_idx - half)
+        idx = list(range(start, min(num_frames, frame_idx + half + 1)))
+        while len(idx) < T:
+            if start == 0:
+                idx.insert(0, idx[0])
+            else:
+                idx.append(idx[-1])
+        return idx[:T]
+
+    def prepare_frame_sequence(self, frames, frame_idx):
+        """list of [H,W,3] arrays -> float32 tensor [1,T,3,H,W] on the device; u8 is scaled by 1/255,
+        float input passes through unscaled (:152-157)."""
+        planes = []
+        for i in self.window_indices(len(frames), frame_idx):
+            f = frames[i]
+            a = f.astype(np.float32) / 255.0 if f.dtype == np.uint8 else f.astype(np.float32)
+            planes.append(torch.from_numpy(a).permute(2, 0, 1))
+        return torch.stack(planes).unsqueeze(0).to(self.device)
+
+    # -- flow -------------------------------------------------------------------------------
+    def _require_model(self):
+        if not self.core.is_model_loaded():
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+
+    def compute_optical_flow(self, frames, frame_idx):
+        """-> numpy [H,W,2] float32, pixels."""
+        self._require_model()
+        flow = self.core.compute_flow_from_tensor(self.prepare_frame_sequence(frames, frame_idx))
+        return flow.permute(1, 2, 0).cpu().numpy()
+
+    def compute_optical_flow_with_progress(self, frames, frame_idx, tile_pbar=None):
+        self._require_model()
+
+        def step(desc, n=0, reset=False):
+            if tile_pbar is not None:
+                tile_pbar.set_description(desc)
+                if reset:
+                    tile_pbar.reset()
+                if n:
+                    tile_pbar.update(n)
+
+        step("Preparing frames", reset=True)
+        batch = self.prepare_frame_sequence(frames, frame_idx)
+        step("Running VideoFlow", 2)
+        flow = self.core.compute_flow_from_tensor(batch)
+        step("Processing output", 1)
+        out = flow.permute(1, 2, 0).cpu().numpy()
+        step("Completed", 1)
+        return out
+
+    def compute_optical_flow_tiled(self, frames, frame_idx, tile_pbar=None, overall_pbar=None):
+        if not self.tile_mode:
+            return self.compute_optical_flow(frames, frame_idx)
+        height, width = frames[frame_idx].shape[:2]
+        tiles = self.calculate_tile_grid(width, height)[4]
+        full = np.zeros((height, width, 2), dtype=np.float32)
+        for k, t in enumerate(tiles):
+            if overall_pbar is not None:
+                overall_pbar.set_description(f"Tile {k + 1}/{len(tiles)} ({t['width']}x{t['height']})")
+            crops = [self.extract_tile(f, t) for f in frames]
+            full[t['y']:t['y'] + t['height'], t['x']:t['x'] + t['width']] = \
+                self.compute_optical_flow_with_progress(crops, frame_idx, tile_pbar)
+            if overall_pbar is not None:
+                overall_pbar.update(1)
+        return full
+
+    # -- HBM-resident clips (extension; results identical to compute_optical_flow) ------------
+    def upload_clip(self, frames):
+        """list of uint8 [H,W,3] frames -> one uint8 [F,H,W,3] tensor on the device (uploaded once;
+        the reference re-uploads T float32 frames per field, 4x the bytes and T-1 of them repeats)."""
+        if any(f.dtype != np.uint8 for f in frames):
+            raise ValueError("upload_clip expects uint8 frames")
+        host = torch.from_numpy(np.stack(frames))
+        if str(self.device).startswith('cuda'):
+            host = host.pin_memory()
+        return host.to(self.device, non_blocking=True)
+
+    def compute_optical_flow_resident(self, clip, frame_idx, tile=None):
+        """Flow field of `frame_idx` from a clip already in HBM -> device tensor [H,W,2] float32.
+        Same window, same /255, same network and index pick as compute_optical_flow; the u8->float
+        conversion runs inside the engine's first kernel."""
+        self._require_model()
+        idx = torch.tensor(self.window_indices(clip.shape[0], frame_idx), device=clip.device)
+        win = clip.index_select(0, idx)
+        if tile is not None:
+            win = win[:, tile['y']:tile['y'] + tile['height'], tile['x']:tile['x'] + tile['width']]
+        H, W = win.shape[1:3]
+        model = self.core.model
+        if H % 8 == 0 and W % 8 == 0 and hasattr(model, "forward_u8"):
+            flows, _ = model.forward_u8(win, return_lowres=False)
+            return flows[0, flows.shape[1] // 2].permute(1, 2, 0)
+        batch = (win.float() / 255.0).permute(0, 3, 1, 2).unsqueeze(0)
+        return self.core.compute_flow_from_tensor(batch).permute(1, 2, 0)
+
+    # -- misc -------------------------------------------------------------------------------
+    def is_model_loaded(self):
+        return self.core.is_model_loaded()
+
+    def get_model_info(self):
+        info = self.core.get_model_info()
+        if info["status"] == "loaded":
+            info.update(tile_mode=self.tile_mode, sequence_length=self.sequence_length,
+                        processor_type="VideoFlowProcessor")
+        return info
+
+    def get_memory_usage(self):
+        return self.core.get_memory_usage()
+
+    def validate_frames(self, frames, frame_idx):
+        """ValueError on anything the reference rejects (:307-351)."""
+        if not isinstance(frames, list):
+            raise ValueError("Frames must be a list of numpy arrays")
+        if not frames:
+            raise ValueError("Frames list cannot be empty")
+        if not 0 <= frame_idx < len(frames):
+            raise ValueError(f"Frame index {frame_idx} out of range [0, {len(frames)-1}]")
+        f = frames[0]
+        if not isinstance(f, np.ndarray):
+            raise ValueError("Frames must be numpy arrays")
+        if f.ndim != 3:
+            raise ValueError(f"Frames must be 3D arrays [H,W,C], got shape {f.shape}")
+        if f.shape[2] != 3:
+            raise ValueError(f"Frames must have 3 color channels, got {f.shape[2]}")
+        if f.dtype not in (np.uint8, np.float32, np.float64):
+            raise ValueError(f"Unsupported frame dtype: {f.dtype}")
+        if f.dtype != np.uint8:
+            lo, hi = float(f.min()), float(f.max())
+            if (hi > 1.0 or lo < 0.0) and not (hi <= 255.0 and lo >= 0.0):
+                raise ValueError("Float frames must be in range [0.0, 1.0] or [0.0, 255.0]")
+
+    def set_tile_mode(self, enabled):
+        self.tile_mode = enabled
+
+    def set_sequence_length(self, length):
+        if length < 1 or length > 10:
+            raise ValueError("Sequence length must be between 1 and 10")
+        self.sequence_length = length

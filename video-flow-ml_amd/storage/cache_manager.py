@@ -1,0 +1,180 @@
+"""Flow cache: .flo / .npz files, completeness check, LOD pyramids.
+
+File formats and names are byte-compatible with reference storage/cache_manager.py:
+  .flo  b'PIEH' + <I width + <I height + float32 [H][W][2]                   (:18-30, :50-64)
+  .npz  np.savez_compressed with members flow f32[H,W,2], frame_idx, shape, dtype   (:33-47, :247-262)
+  names flow_frame_{i:06d}.{flo,npz} and flow_frame_{i:06d}_lod{k}.npz        (:208, :290-299)
+The LOD generator keeps the reference's semantics (:77-161: pad odd sides bottom/right with zero
+weight, 2x2 weighted mean, vectors x0.5) but is vectorised instead of a per-pixel Python loop.
+"""
+import os
+import struct
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover - tqdm is optional plumbing
+    def tqdm(it, **_):
+        return it
+
+
+def _to_numpy(flow):
+    return flow.cpu().numpy() if torch.is_tensor(flow) else flow
+
+
+class FlowFileHandler:
+    @staticmethod
+    def save_flow_flo(flow: np.ndarray, filename: str):
+        flow = _to_numpy(flow)
+        h, w = flow.shape[:2]
+        with open(filename, 'wb') as f:
+            f.write(b'PIEH' + struct.pack('<II', w, h))
+            f.write(flow.astype(np.float32).tobytes())
+
+    @staticmethod
+    def save_flow_npz(flow: np.ndarray, filename: str, frame_idx: Optional[int] = None,
+                      metadata: Optional[Dict[str, Any]] = None):
+        members = {'flow': _to_numpy(flow).astype(np.float32)}
+        if frame_idx is not None:
+            members['frame_idx'] = frame_idx
+        if metadata is not None:
+            members.update(metadata)
+        np.savez_compressed(filename, **members)
+
+    @staticmethod
+    def load_flow_flo(filename: str) -> np.ndarray:
+        with open(filename, 'rb') as f:
+            magic = f.read(4)
+            if magic != b'PIEH':
+                raise ValueError(f"Invalid .flo file magic number: {magic}")
+            w, h = struct.unpack('<II', f.read(8))
+            data = f.read(w * h * 8)
+        return np.frombuffer(data, dtype=np.float32).reshape(h, w, 2)
+
+    @staticmethod
+    def load_flow_npz(filename: str) -> Dict[str, Any]:
+        return dict(np.load(filename))
+
+
+class LODGenerator:
+    @staticmethod
+    def generate_lods(flow: np.ndarray, num_lods: int = 5) -> List[np.ndarray]:
+        """[original, lod1, ...]; each level halves H and W (rounding up) and halves the vectors."""
+        flow = _to_numpy(flow)
+        lods = [flow]
+        cur = flow
+        for _ in range(1, num_lods):
+            h, w = cur.shape[:2]
+            ph, pw = h % 2, w % 2
+            wgt = np.pad(np.ones((h, w), np.float32), ((0, ph), (0, pw)))
+            val = np.pad(cur.astype(np.float32), ((0, ph), (0, pw), (0, 0)))
+            nh, nw = (h + ph) // 2, (w + pw) // 2
+            v4 = val.reshape(nh, 2, nw, 2, 2)
+            w4 = wgt.reshape(nh, 2, nw, 2)
+            # same summation order as np.sum over the 2x2 block in the reference (row-major)
+            num = (v4 * w4[..., None]).transpose(0, 2, 1, 3, 4).reshape(nh, nw, 4, 2)
+            den = w4.transpose(0, 2, 1, 3).reshape(nh, nw, 4)
+            tot = ((den[..., 0] + den[..., 1]) + den[..., 2]) + den[..., 3]
+            acc = ((num[..., 0, :] + num[..., 1, :]) + num[..., 2, :]) + num[..., 3, :]
+            with np.errstate(invalid='ignore', divide='ignore'):
+                out = np.where(tot[..., None] > 0, acc / tot[..., None] * np.float32(0.5), 0).astype(np.float32)
+            lods.append(out)
+            cur = out
+        return lods
+
+
+class FlowCacheManager:
+    def __init__(self):
+        self.file_handler = FlowFileHandler()
+        self.lod_generator = LODGenerator()
+
+    @staticmethod
+    def _frame_file(cache_dir, frame_idx, ext, lod=None):
+        tail = "" if lod is None else f"_lod{lod}"
+        return os.path.join(cache_dir, f"flow_frame_{frame_idx:06d}{tail}.{ext}")
+
+    def generate_cache_path(self, input_path: str, start_frame: int, max_frames: int, sequence_length: int,
+                            fast_mode: bool, tile_mode: bool, model: str = 'videoflow', dataset: str = 'things',
+                            architecture: str = 'mof', variant: str = 'noise') -> str:
+        from .filename_generator import generate_cache_directory
+        return generate_cache_directory(input_path=input_path, start_frame=start_frame, max_frames=max_frames,
+                                        sequence_length=sequence_length, fast_mode=fast_mode, tile_mode=tile_mode,
+                                        model=model, dataset=dataset, architecture=architecture, variant=variant)
+
+    def check_cache_exists(self, cache_dir: str, max_frames: int) -> Tuple[bool, Optional[str], List[int]]:
+        """(complete?, 'npz'|'flo'|None, missing frame indices).  Any .npz in the directory (LOD files
+        included) selects the npz format, as in the reference (:201-206)."""
+        everything = list(range(max_frames))
+        if not os.path.exists(cache_dir):
+            return False, None, everything
+        names = os.listdir(cache_dir)
+        if any(n.endswith('.npz') for n in names):
+            fmt = 'npz'
+        elif any(n.endswith('.flo') for n in names):
+            fmt = 'flo'
+        else:
+            return False, None, everything
+        missing = [i for i in everything if not os.path.exists(self._frame_file(cache_dir, i, fmt))]
+        return (not missing), (None if missing else fmt), missing
+
+    def load_cached_flow(self, cache_dir: str, frame_idx: int, format_type: str = 'auto') -> np.ndarray:
+        npz = self._frame_file(cache_dir, frame_idx, 'npz')
+        flo = self._frame_file(cache_dir, frame_idx, 'flo')
+        if format_type == 'auto':
+            if os.path.exists(npz):
+                format_type = 'npz'
+            elif os.path.exists(flo):
+                format_type = 'flo'
+            else:
+                raise FileNotFoundError(f"No cached flow found for frame {frame_idx}")
+        if format_type == 'npz':
+            return self.file_handler.load_flow_npz(npz)['flow']
+        if format_type == 'flo':
+            return self.file_handler.load_flow_flo(flo)
+        raise ValueError(f"Invalid format_type: {format_type}")
+
+    def save_flow_to_cache(self, flow: np.ndarray, cache_dir: str, frame_idx: int, save_format: str = 'npz'):
+        os.makedirs(cache_dir, exist_ok=True)
+        if save_format in ('flo', 'both'):
+            self.file_handler.save_flow_flo(flow, self._frame_file(cache_dir, frame_idx, 'flo'))
+        if save_format in ('npz', 'both'):
+            meta = {'frame_idx': frame_idx, 'shape': flow.shape, 'dtype': str(flow.dtype)}
+            self.file_handler.save_flow_npz(flow, self._frame_file(cache_dir, frame_idx, 'npz'), frame_idx, meta)
+
+    def save_optical_flow_files(self, flow: np.ndarray, base_filename: str, frame_idx: int, save_format: str):
+        flow = _to_numpy(flow)
+        meta = {'frame_idx': frame_idx, 'shape': flow.shape, 'dtype': str(flow.dtype),
+                'min_flow': float(np.min(flow)), 'max_flow': float(np.max(flow)),
+                'mean_magnitude': float(np.mean(np.sqrt(flow[:, :, 0] ** 2 + flow[:, :, 1] ** 2)))}
+        stem = f"{base_filename}_frame_{frame_idx:06d}"
+        if save_format in ('flo', 'both'):
+            self.file_handler.save_flow_flo(flow, stem + ".flo")
+        if save_format in ('npz', 'both'):
+            self.file_handler.save_flow_npz(flow, stem + ".npz", frame_idx, meta)
+
+    def save_flow_lods(self, lods: List[np.ndarray], cache_dir: str, frame_idx: int):
+        os.makedirs(cache_dir, exist_ok=True)
+        for level, data in enumerate(lods):
+            meta = {'frame_idx': frame_idx, 'lod_level': level, 'shape': data.shape, 'dtype': str(data.dtype)}
+            self.file_handler.save_flow_npz(data, self._frame_file(cache_dir, frame_idx, 'npz', level), frame_idx, meta)
+
+    def load_flow_lod(self, cache_dir: str, frame_idx: int, lod_level: int = 0) -> np.ndarray:
+        name = self._frame_file(cache_dir, frame_idx, 'npz', lod_level)
+        if not os.path.exists(name):
+            raise FileNotFoundError(f"LOD {lod_level} not found for frame {frame_idx}")
+        return self.file_handler.load_flow_npz(name)['flow']
+
+    def check_flow_lods_exist(self, cache_dir: str, max_frames: int, num_lods: int = 5) -> bool:
+        return os.path.exists(cache_dir) and all(
+            os.path.exists(self._frame_file(cache_dir, i, 'npz', k))
+            for i in range(max_frames) for k in range(num_lods))
+
+    def generate_lods_for_cache(self, cache_dir: str, max_frames: int, num_lods: int = 5):
+        print(f"Generating LOD pyramids (levels 0-{num_lods-1}) for {max_frames} frames...")
+        for i in tqdm(range(max_frames), desc="Generating LODs"):
+            self.save_flow_lods(self.lod_generator.generate_lods(self.load_cached_flow(cache_dir, i), num_lods),
+                                cache_dir, i)
+        print(f"LOD generation complete. Generated {num_lods} levels for {max_frames} frames.")

@@ -116,6 +116,37 @@ def _dev(t, dtype=torch.float32):
     return t
 
 
+# -- optional per-launch timing of vfml_conv2d (bench.py's roofline leg) ---------------------------
+_PROFILE = None
+
+
+def profile_begin():
+    """Start recording (kernel variant, algorithmic FLOPs, start/end HIP events) per vfml_conv2d launch.
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """Stop recording; returns {variant: {"launches", "flops", "ms"}} (synchronises)."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for variant, flops, e0, e1 in rec:
+        d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        d["launches"] += 1
+        d["flops"] += flops
+        d["ms"] += e0.elapsed_time(e1)
+    return out
+
+
+def conv_variant(cout):
+    """Which template instantiation vfml_conv2d dispatches to (conv_gemm.hip)."""
+    return "conv_gemm_kernel<128,2,2>" if cout > 64 else ("conv_gemm_kernel<64,2,2>" if cout > 32
+                                                         else "conv_gemm_kernel<32,4,1>")
+
+
 def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, stride=1, pad_h=0, pad_w=0,
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0):
@@ -131,7 +162,16 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.epilogue, d.split, d.out_scale = epilogue, split, out_scale
     d.aux0, d.ld_aux0 = (_ptr(_dev(aux0), aux0_off) if aux0 is not None else None), ld_aux0
     d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
+    if _PROFILE is None:
+        _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
+        return
+    ho = (h + 2 * pad_h - kh) // stride + 1
+    wo = (w + 2 * pad_w - kw) // stride + 1
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
+    e1.record()
+    _PROFILE.append((conv_variant(cout), 2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):
