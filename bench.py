@@ -64,7 +64,8 @@ def main():
     # -- model through the reference's API path ------------------------------------------------
     work = tempfile.mkdtemp(prefix=f"vfml_bench_r{rank}_")
     write_seeded_checkpoint(work, get_cfg(), seed=0)
-    os.chdir(work)
+    cwd = os.getcwd()
+    os.chdir(work)          # the reference resolves VideoFlow_ckpt/ relative to the CWD
     import contextlib
     import io
     from config import DeviceManager
@@ -73,6 +74,7 @@ def main():
         device_name = DeviceManager().get_device("cuda")
         proc = VideoFlowProcessor(device_name if world == 1 else f"cuda:{local_rank}", sequence_length=args.seq)
         proc.load_model()
+    os.chdir(cwd)
 
     # -- synthetic clip, uploaded once ---------------------------------------------------------
     K, Wm, T = args.steps, args.warmup, args.seq
