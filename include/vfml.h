@@ -60,6 +60,17 @@ typedef struct vfml_conv_desc {
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
 
+/* Same contract on the f16 matrix cores with fp32-grade accuracy ("split-f16", 3 MFMAs per
+ * product: x = hi + 2^-11 lo, a*b ~= ah*bh + 2^-11 (ah*bl + al*bh); ~22 mantissa bits).
+ * d->weight is ignored; w_hi / w_lo are the two f16 planes [cout][kp] made by vfml_split_f16
+ * from the [cout][K] weight matrix, kp = K rounded up to a multiple of 8.  Activations stay fp32
+ * in HBM and are split while staged into LDS. */
+int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, void* stream);
+
+/* f32 [rows][k] (row stride ld floats) -> hi = f16(x), lo = f16((x - hi) * 2^11), each [rows][kp],
+ * zero padded from k to kp (kp % 8 == 0). */
+int vfml_split_f16(const float* src, int64_t rows, int k, int ld, void* hi, void* lo, int kp, void* stream);
+
 /* K1: frames -> normalised NHWC4 (4th channel zero):  dst = scale * x + shift.
  * kind 0: src is uint8 [n][H][W][3] (values 0..255, x = u8/255 as the reference does at
  *         processing/videoflow_processor.py:154);  kind 1: src is float32 [n][3][H][W]. */

@@ -30,9 +30,10 @@ def _epe(a, b):
     return (a - b).pow(2).sum(2).sqrt()
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("T,H,W", [(3, 128, 128), (5, 128, 192), (4, 136, 160)])
-def test_model_forward_matches_oracle(gpu, T, H, W):
-    net, ora = _pair()
+def test_model_forward_matches_oracle(gpu, T, H, W, precision):
+    net, ora = _pair(precision=precision)
     g = torch.Generator().manual_seed(T * 1000 + H)
     x = torch.rand(1, T, 3, H, W, generator=g)
     ref, _ = ora(x, {})
@@ -41,6 +42,7 @@ def test_model_forward_matches_oracle(gpu, T, H, W):
     assert got.shape == ref.shape == (1, 2 * (T - 2), 2, H, W)
     e = _epe(got, ref)
     assert torch.isfinite(got).all()
+    print(f"[{precision}] T={T} {H}x{W}: mean EPE {e.mean().item():.3e} px, max {e.max().item():.3e} px")
     assert e.mean().item() < EPE_TOL, f"mean EPE {e.mean().item():.3e} px (max {e.max().item():.3e})"
 
 

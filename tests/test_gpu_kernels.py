@@ -21,6 +21,19 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
+PRECISIONS = ["f32", "f16x3"]     # exact f32 MFMA / split-f16 (3 f16 MFMAs per product)
+CONV_TOL = {"f32": 2e-6, "f16x3": 4e-6}
+
+
+def as_weight(flat, cout, precision):
+    """flat [cout][K] f32 (host or device) -> what hip.conv2d takes for that precision."""
+    from vfml import hip
+    flat = flat.cuda().contiguous()
+    if precision == "f32":
+        return flat
+    return hip.SplitWeight(cout, flat.numel() // cout, flat.device).fill(flat)
+
+
 @pytest.mark.parametrize("cin,cout,kh,kw,stride,ph,pw,H,W,n", [
     (4, 64, 7, 7, 2, 3, 3, 64, 80, 2),      # encoder stem (cin 3 padded to 4)
     (64, 96, 3, 3, 2, 1, 1, 32, 40, 2),     # strided residual conv, cout not a tile multiple
@@ -33,7 +46,8 @@ def rel_err(a, b):
     (256, 124, 3, 3, 1, 1, 1, 16, 20, 1),   # motion encoder tail
     (648, 256, 1, 1, 1, 0, 0, 16, 20, 1),   # corr reduce (K not a multiple of 32)
 ])
-def test_conv2d_matches_torch(gpu, cin, cout, kh, kw, stride, ph, pw, H, W, n):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_conv2d_matches_torch(gpu, precision, cin, cout, kh, kw, stride, ph, pw, H, W, n):
     from vfml import hip
     from vfml.weights import pack_conv_weight
     g = torch.Generator().manual_seed(1)
@@ -43,14 +57,17 @@ def test_conv2d_matches_torch(gpu, cin, cout, kh, kw, stride, ph, pw, H, W, n):
     ref = F.relu(F.conv2d(x, wt, b, stride=stride, padding=(ph, pw)))
     ho, wo = ref.shape[-2:]
     out = torch.full((n * ho * wo * cout,), float("nan"), device=gpu)
-    hip.conv2d(nhwc(x), cin, cin, n, H, W, pack_conv_weight(wt).cuda(), b.cuda(), cout, kh, kw, out, cout,
-               stride=stride, pad_h=ph, pad_w=pw, epilogue=hip.EPI_RELU)
+    hip.conv2d(nhwc(x), cin, cin, n, H, W, as_weight(pack_conv_weight(wt), cout, precision), b.cuda(), cout, kh, kw,
+               out, cout, stride=stride, pad_h=ph, pad_w=pw, epilogue=hip.EPI_RELU)
     got = from_nhwc(out, n, ho, wo, cout)
     assert torch.isfinite(got).all()
-    assert rel_err(got, ref) < 2e-6
+    ref64 = F.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=(ph, pw))).float()
+    assert rel_err(got, ref64) < CONV_TOL[precision]
+    assert rel_err(got, ref) < 2 * CONV_TOL[precision]
 
 
-def test_conv2d_two_sources_slices_and_gru_epilogues(gpu):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_conv2d_two_sources_slices_and_gru_epilogues(gpu, precision):
     """cat([r*h, x]) input from two buffers, output into a channel slice, GRU gate epilogues."""
     from vfml import hip
     from vfml.weights import pack_conv_weight
@@ -67,13 +84,13 @@ def test_conv2d_two_sources_slices_and_gru_epilogues(gpu):
     href = (1 - z) * h + z * q
     hx_d = nhwc(hx)
     zr = torch.empty(n * H * W * 256, device=gpu)
-    wzr = torch.cat([pack_conv_weight(wz), pack_conv_weight(wr)]).cuda()
+    wzr = as_weight(torch.cat([pack_conv_weight(wz), pack_conv_weight(wr)]), 256, precision)
     hip.conv2d(hx_d, 512, 512, n, H, W, wzr, torch.cat([bz, br]).cuda(), 256, 1, 5, zr, 256, pad_w=2,
                epilogue=hip.EPI_GRU_ZR, split=128, aux0=hx_d, ld_aux0=512)
     got_zr = from_nhwc(zr, n, H, W, 256)
     assert rel_err(got_zr[:, :128], z) < 2e-6
     assert rel_err(got_zr[:, 128:], r * h) < 2e-6
-    hip.conv2d(zr, 128, 256, n, H, W, pack_conv_weight(wq).cuda(), bq.cuda(), 128, 1, 5, hx_d, 512, in0_off=128,
+    hip.conv2d(zr, 128, 256, n, H, W, as_weight(pack_conv_weight(wq), 128, precision), bq.cuda(), 128, 1, 5, hx_d, 512, in0_off=128,
                in1=hx_d, c1=384, ld1=512, in1_off=128, pad_w=2, epilogue=hip.EPI_GRU_Q, aux0=zr, ld_aux0=256,
                aux1=hx_d, ld_aux1=512)
     got = from_nhwc(hx_d, n, H, W, 512)
@@ -81,7 +98,8 @@ def test_conv2d_two_sources_slices_and_gru_epilogues(gpu):
     assert torch.equal(got[:, 128:], x)  # the x slice is untouched
 
 
-def test_conv2d_as_gemm_correlation(gpu):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_conv2d_as_gemm_correlation(gpu, precision):
     """out[q][s] = <f1[q], f2[s]> / sqrt(D) with a padded leading dimension (K3)."""
     from vfml import hip
     g = torch.Generator().manual_seed(3)
@@ -89,21 +107,42 @@ def test_conv2d_as_gemm_correlation(gpu):
     f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
     ld = 96
     out = torch.zeros(P * ld, device=gpu)
-    hip.conv2d(f1.cuda().reshape(-1), D, D, 1, 1, P, f2.cuda().reshape(-1), None, S, 1, 1, out, ld,
-               out_scale=1.0 / 16.0)
+    # rows 10.. of a larger target matrix: exercises the row offset the pyramid build uses
+    f2_all = torch.cat([torch.randn(10, D, generator=g), f2])
+    hip.conv2d(f1.cuda().reshape(-1), D, D, 1, 1, P, as_weight(f2_all.reshape(-1), S + 10, precision), None, S, 1, 1,
+               out, ld, out_scale=1.0 / 16.0, weight_off=10 if precision == "f16x3" else 10 * D)
     ref = (f1.double() @ f2.double().t() / 16.0).float()
     got = out.view(P, ld).cpu()
-    assert rel_err(got[:, :S], ref) < 2e-6
+    assert rel_err(got[:, :S], ref) < CONV_TOL[precision]
     assert (got[:, S:] == 0).all()
 
 
 def test_conv2d_rejects_bad_arguments(gpu):
     from vfml import hip
     x = torch.zeros(64, device=gpu)
-    with pytest.raises(RuntimeError, match="multiples of 4"):
-        hip.conv2d(x, 3, 3, 1, 4, 4, x, None, 4, 1, 1, x, 4)
-    with pytest.raises(RuntimeError, match="ldo"):
-        hip.conv2d(x, 4, 4, 1, 4, 4, x, None, 8, 1, 1, x, 4)
+    for w in (x, hip.SplitWeight(8, 4, gpu).fill(x)):
+        with pytest.raises(RuntimeError, match="multiples of 4"):
+            hip.conv2d(x, 3, 3, 1, 4, 4, w, None, 4, 1, 1, x, 4)
+        with pytest.raises(RuntimeError, match="ldo"):
+            hip.conv2d(x, 4, 4, 1, 4, 4, w, None, 8, 1, 1, x, 4)
+    with pytest.raises(RuntimeError, match="rounded up to 8"):
+        hip.conv2d(x, 4, 4, 1, 4, 4, hip.SplitWeight(8, 4, gpu).fill(x), None, 8, 3, 3, x, 8)
+
+
+def test_split_f16_reconstructs_to_22_bits(gpu):
+    """hi + lo/2^11 reproduces x to 2^-21 relative (plus a 2^-24 absolute floor where hi itself is an
+    f16 subnormal, |x| < 6e-5), across 10 orders of magnitude; K padded to 8 with zeros."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(37, 13, generator=g) * torch.logspace(-6, 4, 13)
+    sw = hip.SplitWeight(37, 13, gpu).fill(x.cuda().reshape(-1))
+    assert sw.kp == 16
+    hi = sw.hi.view(37, 16).cpu().double()
+    lo = sw.lo.view(37, 16).cpu().double()
+    rec = hi + lo / 2048.0
+    assert (rec[:, 13:] == 0).all()
+    err = (rec[:, :13] - x.double()).abs()
+    assert (err <= 2.0 ** -21 * x.double().abs() + 2.0 ** -24).all()
 
 
 @pytest.mark.parametrize("kind", ["u8", "f32"])

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvfml_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "conv_gemm.hip", "norm_pool.hip", "flow_ops.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip"]
 
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q = range(7)
 
@@ -66,6 +66,8 @@ def lib():
     L.vfml_last_error.restype = c_char_p
     L.vfml_abi_version.restype = c_int
     L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
+    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]
+    L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_frames_to_nhwc4.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
     L.vfml_instnorm_workspace_bytes.restype = c_int64
     L.vfml_instnorm_workspace_bytes.argtypes = [c_int, c_int, c_int]
@@ -87,7 +89,7 @@ def lib():
 
 
 EXPORTS = [
-    "vfml_conv2d", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
+    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
     "vfml_convex_upsample", "vfml_last_error", "vfml_abi_version",
 ]
@@ -141,10 +143,26 @@ def profile_end():
     return out
 
 
-def conv_variant(cout):
-    """Which template instantiation vfml_conv2d dispatches to (conv_gemm.hip)."""
-    return "conv_gemm_kernel<128,2,2>" if cout > 64 else ("conv_gemm_kernel<64,2,2>" if cout > 32
-                                                         else "conv_gemm_kernel<32,4,1>")
+def conv_variant(cout, split=False):
+    """Which template instantiation vfml_conv2d[_split] dispatches to (conv_gemm[_split].hip)."""
+    base = "conv_gemm_split_kernel" if split else "conv_gemm_kernel"
+    return base + ("<128,2,2>" if cout > 64 else ("<64,2,2>" if cout > 32 else "<32,4,1>"))
+
+
+class SplitWeight:
+    """[rows][k] f32 matrix as two f16 planes [rows][kp] (hi, lo*2^11) for vfml_conv2d_split."""
+
+    def __init__(self, rows, k, device):
+        self.rows, self.k, self.kp = rows, k, (k + 7) // 8 * 8
+        self.hi = torch.empty(rows * self.kp, dtype=torch.float16, device=device)
+        self.lo = torch.empty(rows * self.kp, dtype=torch.float16, device=device)
+
+    def fill(self, src, src_off=0, ld=None):
+        """src: flat f32 device tensor holding [rows][k] at float offset src_off with row stride ld."""
+        _check(lib().vfml_split_f16(_ptr(_dev(src), src_off), self.rows, self.k, ld or self.k,
+                                    c_void_p(self.hi.data_ptr()), c_void_p(self.lo.data_ptr()), self.kp, _stream()),
+               "vfml_split_f16")
+        return self
 
 
 def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, stride=1, pad_h=0, pad_w=0,
@@ -156,22 +174,33 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
     d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
     d.n, d.h, d.w = n, h, w
-    d.weight, d.bias = _ptr(_dev(weight), weight_off), (_ptr(_dev(bias)) if bias is not None else None)
+    is_split = isinstance(weight, SplitWeight)
+    d.weight = None if is_split else _ptr(_dev(weight), weight_off)
+    d.bias = _ptr(_dev(bias)) if bias is not None else None
     d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w = cout, kh, kw, stride, pad_h, pad_w
     d.out, d.ldo = _ptr(_dev(out), out_off), ldo
     d.epilogue, d.split, d.out_scale = epilogue, split, out_scale
     d.aux0, d.ld_aux0 = (_ptr(_dev(aux0), aux0_off) if aux0 is not None else None), ld_aux0
     d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
+    if is_split:
+        # weight_off counts rows of the split planes (each row kp halves)
+        def launch():
+            _check(lib().vfml_conv2d_split(ctypes.byref(d), c_void_p(weight.hi.data_ptr() + 2 * weight_off * weight.kp),
+                                           c_void_p(weight.lo.data_ptr() + 2 * weight_off * weight.kp), weight.kp,
+                                           _stream()), "vfml_conv2d_split")
+    else:
+        def launch():
+            _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
     if _PROFILE is None:
-        _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
+        launch()
         return
     ho = (h + 2 * pad_h - kh) // stride + 1
     wo = (w + 2 * pad_w - kw) // stride + 1
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
+    launch()
     e1.record()
-    _PROFILE.append((conv_variant(cout), 2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
+    _PROFILE.append((conv_variant(cout, is_split), 2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):

@@ -65,7 +65,9 @@ class MOFNetHIP(_Holder):
 
     def _pack(self, device):
         """Repack every conv weight into the kernels' [cout][kh][kw][cin] order (once per load)."""
-        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        split = self._precision() == "f16x3"
+        key = (str(device), split, tuple(p._version for p in self.parameters()),
+               tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is not None and self._packed_key == key:
             return self._packed
         P = {}
@@ -90,8 +92,20 @@ class MOFNetHIP(_Holder):
             wz, bz = P[f"update_block.gru.convz{k}"]
             wr, br = P[f"update_block.gru.convr{k}"]
             P[f"update_block.gru.convzr{k}"] = (torch.cat([wz, wr]).contiguous(), torch.cat([bz, br]).contiguous())
+        if split:
+            # split-f16 planes (hi, lo*2^11) of every [cout][K] matrix, made once per load
+            with torch.cuda.device(device):
+                for name, (wflat, b) in list(P.items()):
+                    cout = b.numel()
+                    P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat), b)
         self._packed, self._packed_key = P, key
         return P
+
+    def _precision(self):
+        p = getattr(self.cfg, "precision", "f16x3")
+        if p not in ("f16x3", "f32"):
+            raise ValueError(f"cfg.precision must be 'f16x3' or 'f32', got {p!r}")
+        return p
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, name, numel, device, dtype=torch.float32, zero=False):
@@ -225,12 +239,24 @@ class MOFNetHIP(_Holder):
             # K3/K4 correlation pyramids: rows = (centre frame, query cell)
             pyr = {d: [self._buf(f"pyr_{d}{l}", MP * ldl[l], dev) for l in range(L)] for d in ("f", "b")}
             scale = 1.0 / float(D) ** 0.5
+            if self._precision() == "f16x3":
+                tgt_w = []
+                for l in range(L):
+                    key = ("tgt_split", l, N * Sl[l])
+                    sw = self._ws.get(key)
+                    if sw is None or sw.hi.device != dev:
+                        sw = self._ws[key] = hip.SplitWeight(N * Sl[l], D, dev)
+                    tgt_w.append(sw.fill(fl[l]))
+                w_row = lambda tgt, l: tgt * Sl[l]            # row offset into the split planes
+            else:
+                tgt_w = fl
+                w_row = lambda tgt, l: tgt * Sl[l] * D        # float offset into the f32 features
             for c in range(1, N - 1):
                 for d, tgt in (("f", c + 1), ("b", c - 1)):
                     for l in range(L):
-                        hip.conv2d(fmap, D, D, 1, 1, Pn, fl[l], None, Sl[l], 1, 1, pyr[d][l], ldl[l],
+                        hip.conv2d(fmap, D, D, 1, 1, Pn, tgt_w[l], None, Sl[l], 1, 1, pyr[d][l], ldl[l],
                                    in0_off=c * Pn * D, out_off=(c - 1) * Pn * ldl[l], out_scale=scale,
-                                   weight_off=tgt * Sl[l] * D)
+                                   weight_off=w_row(tgt, l))
 
             # K2 context encoder on the centre frames -> hx[:, 0:128] = tanh, hx[:, 128:256] = relu
             hx = self._buf("hx", MP * 512, dev)
