@@ -60,16 +60,20 @@ typedef struct vfml_conv_desc {
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
 
-/* Same contract on the f16 matrix cores with fp32-grade accuracy ("split-f16", 3 MFMAs per
- * product: x = hi + 2^-11 lo, a*b ~= ah*bh + 2^-11 (ah*bl + al*bh); ~22 mantissa bits).
- * d->weight is ignored; w_hi / w_lo are the two f16 planes [cout][kp] made by vfml_split_f16
- * from the [cout][K] weight matrix, kp = K rounded up to a multiple of 8.  Activations stay fp32
- * in HBM and are split while staged into LDS. */
-int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, void* stream);
+/* Same contract on the f16 matrix cores with fp32-grade accuracy ("split-f16": x = hi + lo with
+ * hi = f16(x), lo = f16(x - hi); a*b ~= ah*bh + ah*bl + al*bh, 3 MFMAs per product, ~22 mantissa
+ * bits).  d->weight is ignored; w_hi / w_lo are the two f16 planes [cout][kp] made by
+ * vfml_split_f16 from the [cout][K] weight matrix times `w_scale`, kp = K rounded up to a multiple
+ * of 32; the kernel divides the accumulator by w_scale.  Activations stay fp32 in HBM and are split
+ * while staged into LDS. */
+int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
+                      void* stream);
 
-/* f32 [rows][k] (row stride ld floats) -> hi = f16(x), lo = f16((x - hi) * 2^11), each [rows][kp],
- * zero padded from k to kp (kp % 8 == 0). */
-int vfml_split_f16(const float* src, int64_t rows, int k, int ld, void* hi, void* lo, int kp, void* stream);
+/* y = scale * src (f32 [rows][k], row stride ld floats) -> hi = f16(y), lo = f16(y - hi), each
+ * [rows][kp], zero padded from k to kp (kp % 32 == 0).  A power-of-two scale that brings max|y|
+ * near 2^14 keeps the lo halves out of the f16 subnormal range. */
+int vfml_split_f16(const float* src, int64_t rows, int k, int ld, float scale, void* hi, void* lo, int kp,
+                   void* stream);
 
 /* K1: frames -> normalised NHWC4 (4th channel zero):  dst = scale * x + shift.
  * kind 0: src is uint8 [n][H][W][3] (values 0..255, x = u8/255 as the reference does at

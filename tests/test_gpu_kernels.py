@@ -22,7 +22,7 @@ def rel_err(a, b):
 
 
 PRECISIONS = ["f32", "f16x3"]     # exact f32 MFMA / split-f16 (3 f16 MFMAs per product)
-CONV_TOL = {"f32": 2e-6, "f16x3": 4e-6}
+CONV_TOL = {"f32": 2e-6, "f16x3": 5e-6}
 
 
 def as_weight(flat, cout, precision):
@@ -31,7 +31,8 @@ def as_weight(flat, cout, precision):
     flat = flat.cuda().contiguous()
     if precision == "f32":
         return flat
-    return hip.SplitWeight(cout, flat.numel() // cout, flat.device).fill(flat)
+    return hip.SplitWeight(cout, flat.numel() // cout, flat.device).fill(
+        flat, scale=hip.SplitWeight.auto_scale(float(flat.abs().max())))
 
 
 @pytest.mark.parametrize("cin,cout,kh,kw,stride,ph,pw,H,W,n", [
@@ -82,20 +83,24 @@ def test_conv2d_two_sources_slices_and_gru_epilogues(gpu, precision):
     r = torch.sigmoid(F.conv2d(hx, wr, br, padding=(0, 2)))
     q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq, bq, padding=(0, 2)))
     href = (1 - z) * h + z * q
-    hx_d = nhwc(hx)
-    zr = torch.empty(n * H * W * 256, device=gpu)
+    # one state buffer per cell: [ z | r*h | h | x ]  (the layout the engine uses; the two sources of
+    # the q convolution are channel slices of the same allocation)
+    LD, Z, RH, HH, X = 768, 0, 128, 256, 384
+    G = torch.zeros(n, H, W, LD)
+    G[..., HH:] = hx.permute(0, 2, 3, 1)
+    G = G.cuda().reshape(-1)
     wzr = as_weight(torch.cat([pack_conv_weight(wz), pack_conv_weight(wr)]), 256, precision)
-    hip.conv2d(hx_d, 512, 512, n, H, W, wzr, torch.cat([bz, br]).cuda(), 256, 1, 5, zr, 256, pad_w=2,
-               epilogue=hip.EPI_GRU_ZR, split=128, aux0=hx_d, ld_aux0=512)
-    got_zr = from_nhwc(zr, n, H, W, 256)
-    assert rel_err(got_zr[:, :128], z) < 2e-6
-    assert rel_err(got_zr[:, 128:], r * h) < 2e-6
-    hip.conv2d(zr, 128, 256, n, H, W, as_weight(pack_conv_weight(wq), 128, precision), bq.cuda(), 128, 1, 5, hx_d, 512, in0_off=128,
-               in1=hx_d, c1=384, ld1=512, in1_off=128, pad_w=2, epilogue=hip.EPI_GRU_Q, aux0=zr, ld_aux0=256,
-               aux1=hx_d, ld_aux1=512)
-    got = from_nhwc(hx_d, n, H, W, 512)
-    assert rel_err(got[:, :128], href) < 3e-6
-    assert torch.equal(got[:, 128:], x)  # the x slice is untouched
+    hip.conv2d(G, 512, LD, n, H, W, wzr, torch.cat([bz, br]).cuda(), 256, 1, 5, G, LD, in0_off=HH, out_off=Z,
+               pad_w=2, epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=LD, aux0_off=HH)
+    got = G.view(n, H, W, LD).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got[:, Z:Z + 128], z) < 2e-6
+    assert rel_err(got[:, RH:RH + 128], r * h) < 2e-6
+    hip.conv2d(G, 128, LD, n, H, W, as_weight(pack_conv_weight(wq), 128, precision), bq.cuda(), 128, 1, 5, G, LD,
+               in0_off=RH, out_off=HH, in1=G, c1=384, ld1=LD, in1_off=X, pad_w=2, epilogue=hip.EPI_GRU_Q,
+               aux0=G, ld_aux0=LD, aux0_off=Z, aux1=G, ld_aux1=LD, aux1_off=HH)
+    got = G.view(n, H, W, LD).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got[:, HH:HH + 128], href) < 4e-6
+    assert torch.equal(got[:, X:], x)  # the x slice is untouched
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -125,24 +130,24 @@ def test_conv2d_rejects_bad_arguments(gpu):
             hip.conv2d(x, 3, 3, 1, 4, 4, w, None, 4, 1, 1, x, 4)
         with pytest.raises(RuntimeError, match="ldo"):
             hip.conv2d(x, 4, 4, 1, 4, 4, w, None, 8, 1, 1, x, 4)
-    with pytest.raises(RuntimeError, match="rounded up to 8"):
+    with pytest.raises(RuntimeError, match="rounded up to 32"):
         hip.conv2d(x, 4, 4, 1, 4, 4, hip.SplitWeight(8, 4, gpu).fill(x), None, 8, 3, 3, x, 8)
 
 
 def test_split_f16_reconstructs_to_22_bits(gpu):
-    """hi + lo/2^11 reproduces x to 2^-21 relative (plus a 2^-24 absolute floor where hi itself is an
-    f16 subnormal, |x| < 6e-5), across 10 orders of magnitude; K padded to 8 with zeros."""
+    """(hi + lo)/scale reproduces x to 2^-21 relative (plus an absolute floor of one f16 subnormal
+    step, where lo itself is subnormal), across 10 orders of magnitude; K padded to 8 with zeros."""
     from vfml import hip
     g = torch.Generator().manual_seed(11)
     x = torch.randn(37, 13, generator=g) * torch.logspace(-6, 4, 13)
-    sw = hip.SplitWeight(37, 13, gpu).fill(x.cuda().reshape(-1))
-    assert sw.kp == 16
-    hi = sw.hi.view(37, 16).cpu().double()
-    lo = sw.lo.view(37, 16).cpu().double()
-    rec = hi + lo / 2048.0
+    sw = hip.SplitWeight(37, 13, gpu).fill(x.cuda().reshape(-1), scale=0.25)
+    assert sw.kp == 32
+    hi = sw.hi.view(37, 32).cpu().double()
+    lo = sw.lo.view(37, 32).cpu().double()
+    rec = (hi + lo) / 0.25
     assert (rec[:, 13:] == 0).all()
     err = (rec[:, :13] - x.double()).abs()
-    assert (err <= 2.0 ** -21 * x.double().abs() + 2.0 ** -24).all()
+    assert (err <= 2.0 ** -21 * x.double().abs() + 2.0 ** -22).all()
 
 
 @pytest.mark.parametrize("kind", ["u8", "f32"])

@@ -1,0 +1,39 @@
+"""Micro-benchmark of vfml_conv2d[_split] on chosen shapes (dev tool, GPU only)."""
+import sys, os, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, ROOT)
+import torch
+from vfml import hip
+
+def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20):
+    ld = ld or cin
+    x = torch.randn(n * h * w * ld, device="cuda")
+    wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout, device="cuda")
+    wobj = wt if prec == "f32" else hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
+    out = torch.empty(n * h * w * cout, device="cuda")
+    def run():
+        hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * n * h * w * kh * kw * cin * cout
+    print(f"{name:46s} M={n*h*w:8d} K={kh*kw*cin:5d} cout={cout:5d}  {ms*1000:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
+
+if __name__ == "__main__":
+    bench("gru 1x5 c512->256 (3x135x240)", 3, 135, 240, 512, 256, 1, 5)
+    bench("gru 1x5 c512->256 (3x135x240) ld768", 3, 135, 240, 512, 256, 1, 5, ld=768)
+    bench("same M, tiny images (760x8x16): A L2-resident", 760, 8, 16, 512, 256, 1, 5)
+    bench("1x1 c2560->256 (K same, no tap reuse)", 3, 135, 240, 2560, 256, 1, 1)
+    bench("1x1 c512->256", 3, 135, 240, 512, 256, 1, 1)
+    bench("1x5 c512->128", 3, 135, 240, 512, 128, 1, 5)
+    bench("3x3 c256->256", 3, 135, 240, 256, 256, 3, 3)
+    bench("3x3 c256->256 tiny images", 760, 8, 16, 256, 256, 3, 3)
+    bench("3x3 c64->64 half-res 5 frames", 5, 540, 960, 64, 64, 3, 3)
+    bench("gemm 32400x32400x256", 1, 1, 32400, 256, 32400, 1, 1, reps=5)
+    bench("gemm 32400x4096x256", 1, 1, 32400, 256, 4096, 1, 1, reps=5)
+    bench("f32 gru 1x5 c512->256", 3, 135, 240, 512, 256, 1, 5, prec="f32")

@@ -1,0 +1,15 @@
+"""Run one conv shape repeatedly (target for rocprofv3 --pmc). GPU only."""
+import sys, os, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, ROOT)
+import torch
+from vfml import hip
+n, h, w, cin, cout, kh, kw = 3, 135, 240, 512, 256, 1, 5
+x = torch.randn(n * h * w * cin, device="cuda")
+wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
+b = torch.randn(cout, device="cuda")
+wobj = hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
+out = torch.empty(n * h * w * cout, device="cuda")
+for _ in range(5):
+    hip.conv2d(x, cin, cin, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU)
+torch.cuda.synchronize()

@@ -1,20 +1,30 @@
-// Implicit-GEMM convolution / NT-GEMM on the CDNA4 f16 matrix cores with fp32-grade accuracy
-// ("split-f16": every operand x is carried as hi = f16(x) and lo = f16((x - hi) * 2^11), and
-//   a*b ~= a_hi*b_hi + 2^-11 * (a_hi*b_lo + a_lo*b_hi)      (a_lo*b_lo ~ 2^-22 |ab| is dropped)
-// f16 x f16 products are exact in the f32 accumulator, so the result carries ~22 mantissa bits:
-// within a few ulp of an f32 conv, at 3 v_mfma_f32_32x32x16_f16 (1024 FLOP/clk/SIMD each) per
-// product instead of one v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD): 16/3 = 5.3x the f32 MFMA rate.
-// Scaling lo by 2^11 keeps it a normal f16 whenever hi is, so nothing depends on denormals.
+// Implicit-GEMM convolution / NT-GEMM on the CDNA4 f16 matrix cores with fp32-grade accuracy.
+//
+// "split-f16": every operand x is carried as two halves, hi = f16(x) and lo = f16(x - hi), and
+//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi                 (a_lo*b_lo ~ 2^-22 |ab| is dropped)
+// f16 x f16 products are exact in the f32 accumulator, so the result carries ~22 mantissa bits,
+// at 3 v_mfma_f32_32x32x16_f16 (1024 FLOP/clk/SIMD each) per product instead of one
+// v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD): 16/3 = 5.3x the f32 MFMA rate, one accumulator.
+// lo is an f16 subnormal when |x| < 2^-3 (absolute error <= 2^-25 there; gfx950's MFMA takes f16
+// subnormals unflushed - measured).  The pre-split operand (weights, correlation targets) is
+// scaled by a power of two at split time so that its lo halves are normal numbers; the epilogue
+// multiplies the accumulator by the inverse (exact).
 //
 // Activations stay fp32 NHWC in HBM and are split while being staged into LDS; weights (and the
 // pooled target features of the correlation GEMM) are pre-split once by vfml_split_f16 into two
-// f16 planes [cout][Kp], Kp = K rounded up to 8, zero padded.
+// f16 planes [cout][Kp], Kp = K rounded up to 32 (one K step), zero padded.
 //
 // Tiling: 128 pixels x BN channels per 256-thread workgroup, K stepped by 32.  LDS image per
 // operand plane: [k/8][row] 16-byte units (8 halves), row stride padded by 2 units: the staging
 // write of 8 consecutive lanes (4 k-groups x 2 rows) covers all 32 banks, a wave's fragment read is
 // 32 consecutive units (conflict-free ds_read_b128) and is exactly one MFMA operand
 // (lane l: row l&31, k = 8*(l>>5)+j).
+// Pipeline: two register staging sets; the global loads of K step k+2 are issued before the MFMAs
+// of step k, the (already landed) loads of step k+1 are split and written to the other LDS
+// buffer after them; one barrier per K step.  Loads are unconditional (padding taps / K tails read
+// a zero line) so that no load sits behind a divergent branch.
+// Epilogue: the accumulator tile is transposed through LDS and written as float4 rows (bias,
+// activation and the GRU gate math applied on the way).
 #include <hip/hip_fp16.h>
 #include "vfml_common.h"
 
@@ -27,8 +37,15 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int KG = BK / 8;  // 16-byte units (8 halves) per row per K step
-constexpr float LO_SCALE = 2048.0f;
-constexpr float LO_INV = 1.0f / 2048.0f;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: an offset beyond num_records returns zeros, which is how
+// padding taps, K tails and out-of-range rows/columns are filled (no branch, no select on the data).
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, 0, 0));
+}
+constexpr int OOB = 0x7fffffff;   // >= any num_records we create (all < 2^31 bytes)
 
 struct SplitArgs {
   const float* in0; const float* in1;
@@ -37,12 +54,15 @@ struct SplitArgs {
   float* out;
   int c0, ld0, c1, ld1, ctot;
   int H, W, ho, wo;
-  int kw, stride, pad_h, pad_w;
+  int kh, kw, stride, pad_h, pad_w;
   int M, K, Kp, cout;
+  int d0off, d1off;             // float offsets of in0 / in1 from the common descriptor base (in0 field)
+  int bytes0, bytesw;           // descriptor extents: sources (both, from the base) and weight planes
   int ldo, ld_aux0, ld_aux1;
   int epilogue, split;
-  float out_scale;
+  float out_scale, w_inv;
   int mtiles, ntiles;
+  int vec_ok;  // out/aux/bias 16-byte aligned and ldo, ld_aux % 4 == 0 -> float4 epilogue
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -52,21 +72,37 @@ union U8 {
   h16x2 p[4];
 };
 
-// x (4 floats) -> hi/lo halves written at element offset `at` (0 or 4) of the 8-wide units
+// x (4 floats) -> hi/lo halves at element offset `at` (0 or 4) of the 8-wide units
 __device__ __forceinline__ void split4(const f32x4 x, U8& hi, U8& lo, int at) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const float a = x[2 * e], b = x[2 * e + 1];
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ra = (a - (float)h[0]) * LO_SCALE;
-    const float rb = (b - (float)h[1]) * LO_SCALE;
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    // a - float(h): written as fma(float(h), -1, a) so that it selects v_fma_mix_f32 (f16 source
+    // operand, no separate v_cvt_f32_f16)
+    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -1.0f, a),
+                                                __builtin_fmaf((float)h[1], -1.0f, b));
     hi.p[at / 2 + e] = __builtin_bit_cast(h16x2, h);
     lo.p[at / 2 + e] = __builtin_bit_cast(h16x2, l);
   }
 }
 
-template <int BN, int WM, int WN>
+__device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float x0, float x1) {
+  switch (epilogue) {
+    case VFML_EPI_RELU: return fmaxf(v, 0.f);
+    case VFML_EPI_TANH: return tanhf(v);
+    case VFML_EPI_SIGMOID: return sigmoidf_(v);
+    case VFML_EPI_TANH_RELU: return lowhalf ? tanhf(v) : fmaxf(v, 0.f);
+    case VFML_EPI_GRU_ZR: v = sigmoidf_(v); return lowhalf ? v : v * x0;
+    case VFML_EPI_GRU_Q: return (1.f - x0) * x1 + x0 * tanhf(v);
+    default: return v;
+  }
+}
+
+// BIGC: every source row has >= BK channels, so a K step never spans more than two taps and the
+// (channel, tap) state advances without divisions.  !BIGC (4-channel stem / flow convs) recomputes
+// it by division each step.
+template <int BN, int WM, int WN, bool BIGC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs a) {
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
@@ -77,12 +113,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
   constexpr int RSB = BN + 2;
   constexpr int SA = KG * RSA;  // units per A plane per buffer
   constexpr int SB = KG * RSB;
+  constexpr int LDC = BN + 4;   // epilogue tile row stride (floats)
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   h16x8* sAh = reinterpret_cast<h16x8*>(smem_raw);
   h16x8* sAl = sAh + 2 * SA;
   h16x8* sBh = sAl + 2 * SA;
   h16x8* sBl = sBh + 2 * SB;
+  float* sC = reinterpret_cast<float*>(smem_raw);
 
   const int nwg = a.mtiles * a.ntiles;
   int bid = blockIdx.x;
@@ -101,24 +139,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
 
   // Per-row gather state, fixed for the whole K loop.  All A offsets are 32-bit element offsets
   // (the host checks that every source spans < 2^31 floats).
-  int iy0[AU], ix0[AU], rp0[AU], rp1[AU];
+  // tapok[i] bit (ky*kw+kx) = that tap of row i lies inside the image (kh*kw <= 64, host check)
+  int rp0[AU], rp1[AU];
+  unsigned long long tapok[AU];
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
     const int m = m0 + lrow + 64 * i;
+    int iy0[1], ix0[1];   // (kept as arrays of one to reuse the expressions below)
+    tapok[i] = 0ull;
     if (m < a.M) {
       const int hw = a.ho * a.wo;
       const int n = m / hw;
       const int rem = m - n * hw;
       const int oy = rem / a.wo;
       const int ox = rem - oy * a.wo;
-      iy0[i] = oy * a.stride - a.pad_h;
-      ix0[i] = ox * a.stride - a.pad_w;
-      const int pix = (n * a.H + iy0[i]) * a.W + ix0[i];
-      rp0[i] = pix * a.ld0;
-      rp1[i] = pix * a.ld1;
+      iy0[0] = oy * a.stride - a.pad_h;
+      ix0[0] = ox * a.stride - a.pad_w;
+      const int pix = (n * a.H + iy0[0]) * a.W + ix0[0];
+      rp0[i] = pix * a.ld0 + a.d0off;
+      rp1[i] = pix * a.ld1 + a.d1off;
+      for (int ky = 0; ky < a.kh; ++ky)
+        for (int kx = 0; kx < a.kw; ++kx)
+          if ((unsigned)(iy0[0] + ky) < (unsigned)a.H && (unsigned)(ix0[0] + kx) < (unsigned)a.W)
+            tapok[i] |= 1ull << (ky * a.kw + kx);
     } else {
-      iy0[i] = -(1 << 28);
-      ix0[i] = 0;
       rp0[i] = rp1[i] = 0;
     }
   }
@@ -133,36 +177,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
     kky[hf] = tap / a.kw;
     kkx[hf] = tap - kky[hf] * a.kw;
   }
-  const bool big_c = a.ctot >= BK;
-  int colKp[BUN];
+  // Byte offset of this thread's B rows; rows past cout start beyond the descriptor (planes are
+  // < 1 GiB, host check), so adding the k offset keeps them out of range: zeros, no select.
+  int colbase[BUN];
 #pragma unroll
-  for (int i = 0; i < BUN; ++i) colKp[i] = (n0 + lrow + 64 * i) * a.Kp;   // cout * Kp < 2^31 (host check)
+  for (int i = 0; i < BUN; ++i) {
+    const int col = n0 + lrow + 64 * i;
+    const bool colok = (BU > 0 || lrow < BN) && col < a.cout;
+    colbase[i] = colok ? col * a.Kp * 2 : 0x40000000;
+  }
 
-  f32x4 ra[AU][2];
-  h16x8 rbh[BUN], rbl[BUN];
+  struct Stage {
+    f32x4 a[AU][2];
+    h16x8 bh[BUN], bl[BUN];
+  };
+  Stage st0, st1;
 
-  auto load_tile = [&](int k0) {
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, a.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.whi), 0, a.bytesw, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wlo), 0, a.bytesw, 0x00020000);
+
+  // Issues the loads of the K step starting at k0 (must be called in increasing k0 order).
+  auto load_tile = [&](Stage& s, int k0) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const bool kok = k0 + kg * 8 + hf * 4 < a.K;
       int c = kc[hf];
       const int ky = kky[hf], kx = kkx[hf];
       const bool s1 = c >= a.c0;
-      const float* src = s1 ? a.in1 : a.in0;
       const int ld = s1 ? a.ld1 : a.ld0;
       if (s1) c -= a.c0;
       const int tapoff = (ky * a.W + kx) * ld + c;
+      const int tap = kok ? ky * a.kw + kx : 63;   // k >= K: tap >= kh*kw, bit never set (host: kh*kw < 64)
 #pragma unroll
       for (int i = 0; i < AU; ++i) {
-        const int iy = iy0[i] + ky;
-        const int ix = ix0[i] + kx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          v = *reinterpret_cast<const f32x4*>(src + ((s1 ? rp1[i] : rp0[i]) + tapoff));
-        ra[i][hf] = v;
+        const bool ok = (tapok[i] >> tap) & 1ull;
+        const int off = ((s1 ? rp1[i] : rp0[i]) + tapoff) * 4;
+        s.a[i][hf] = __builtin_bit_cast(f32x4, bload16(r0, ok ? off : OOB));
       }
-      // advance to the next K step
-      if (big_c) {
+      if (BIGC) {
         int cn = kc[hf] + BK;
         if (cn >= a.ctot) {
           cn -= a.ctot;
@@ -180,33 +233,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
         kkx[hf] = tap - kky[hf] * a.kw;
       }
     }
-    const int kb = k0 + kg * 8;
+    // Kp is a multiple of BK and the planes are zero padded, so every k of a K step < nk exists;
+    // the one prefetch past the end (k0 = nk*BK) lands in the next row or beyond the descriptor and
+    // is never consumed.
+    const int kb2 = (k0 + kg * 8) * 2;
 #pragma unroll
     for (int i = 0; i < BUN; ++i) {
-      const int col = n0 + lrow + 64 * i;
-      h16x8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-      if ((BU > 0 || lrow < BN) && kb < a.Kp && col < a.cout) {
-        vh = *reinterpret_cast<const h16x8*>(a.whi + (colKp[i] + kb));
-        vl = *reinterpret_cast<const h16x8*>(a.wlo + (colKp[i] + kb));
-      }
-      rbh[i] = vh;
-      rbl[i] = vl;
+      s.bh[i] = __builtin_bit_cast(h16x8, bload16(rh, colbase[i] + kb2));
+      s.bl[i] = __builtin_bit_cast(h16x8, bload16(rl, colbase[i] + kb2));
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& s, int buf) {
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
       U8 hi, lo;
-      split4(ra[i][0], hi, lo, 0);
-      split4(ra[i][1], hi, lo, 4);
+      split4(s.a[i][0], hi, lo, 0);
+      split4(s.a[i][1], hi, lo, 4);
       sAh[buf * SA + kg * RSA + lrow + 64 * i] = hi.v;
       sAl[buf * SA + kg * RSA + lrow + 64 * i] = lo.v;
     }
 #pragma unroll
     for (int i = 0; i < BUN; ++i) {
       if (BU > 0 || lrow < BN) {
-        sBh[buf * SB + kg * RSB + lrow + 64 * i] = rbh[i];
-        sBl[buf * SB + kg * RSB + lrow + 64 * i] = rbl[i];
+        sBh[buf * SB + kg * RSB + lrow + 64 * i] = s.bh[i];
+        sBl[buf * SB + kg * RSB + lrow + 64 * i] = s.bl[i];
       }
     }
   };
@@ -218,25 +268,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
   const int r = lane & 31;
   const int half = lane >> 5;
 
-  f32x16 acc[TM][TN], accx[TM][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        acc[i][j][e] = 0.f;
-        accx[i][j][e] = 0.f;
-      }
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (a.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+  auto compute = [&](int buf) {
     const int oa = buf * SA + wm * (BM / WM) + r;
     const int ob = buf * SB + wn * (BN / WN) + r;
 #pragma unroll
@@ -257,54 +297,107 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-          accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  // Two staging sets, two K steps of prefetch: the loads of step k+2 are issued before the MFMAs of
+  // step k; the loads of step k+1 (issued one iteration earlier) are split and written to the other
+  // LDS buffer after them.  Loads past K are descriptor-out-of-range (zeros, no traffic), so the
+  // loop body has no conditionals (a conditional load makes the compiler's s_waitcnt placement
+  // assume the not-taken path and drain the fresh loads too) and the step count is rounded up to
+  // even (one all-zero step when odd) so that the unrolled pair has a single exit.
+  const int nk = ((a.K + BK - 1) / BK + 1) & ~1;
+  load_tile(st0, 0);
+  load_tile(st1, BK);
+  store_tile(st0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    load_tile(st0, (kt + 2) * BK);
+    __builtin_amdgcn_sched_barrier(0);   // loads first ...
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);   // ... their consumers (split + LDS write) only after the MFMAs
+    store_tile(st1, 1);
+    __syncthreads();
+    load_tile(st1, (kt + 3) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(st0, 0);
     __syncthreads();
   }
 
+  // ---- epilogue: accumulators -> LDS tile -> float4 rows ------------------------------------
+  // (every wave passed the loop's final barrier, so the staging buffers are free)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / WN) + j * 32 + r;
-    if (col >= a.cout) continue;
-    const float bias = a.bias ? a.bias[col] : 0.f;
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (row >= a.M) continue;
-        float v = (acc[i][j][e] + accx[i][j][e] * LO_INV + bias) * a.out_scale;
-        switch (a.epilogue) {
-          case VFML_EPI_RELU: v = fmaxf(v, 0.f); break;
-          case VFML_EPI_TANH: v = tanhf(v); break;
-          case VFML_EPI_SIGMOID: v = sigmoidf_(v); break;
-          case VFML_EPI_TANH_RELU: v = col < a.split ? tanhf(v) : fmaxf(v, 0.f); break;
-          case VFML_EPI_GRU_ZR:
-            v = sigmoidf_(v);
-            if (col >= a.split) v *= a.aux0[(int64_t)row * a.ld_aux0 + (col - a.split)];
-            break;
-          case VFML_EPI_GRU_Q: {
-            const float z = a.aux0[(int64_t)row * a.ld_aux0 + col];
-            const float h = a.aux1[(int64_t)row * a.ld_aux1 + col];
-            v = (1.f - z) * h + z * tanhf(v);
-          } break;
-          default: break;
+        const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int col = wn * (BN / WN) + j * 32 + r;
+        sC[row * LDC + col] = acc[i][j][e];
+      }
+  __syncthreads();
+
+  constexpr int C4 = BN / 4;         // float4 columns per tile row
+  constexpr int RPP = 256 / C4;      // rows per pass
+  const int c4 = t % C4;
+  const int gcol = n0 + c4 * 4;
+  if (gcol >= a.cout) return;
+  const bool full4 = a.vec_ok && gcol + 4 <= a.cout;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (gcol + e < a.cout) bias4[e] = a.bias[gcol + e];
+  }
+  const int epi = a.epilogue;
+  const bool lowhalf = gcol < a.split;   // split is a multiple of 4: a float4 never straddles it
+  for (int row = t / C4; row < BM; row += RPP) {
+    const int grow = m0 + row;
+    if (grow >= a.M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c4 * 4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + bias4[e]) * a.out_scale;
+    float* o = a.out + (int64_t)grow * a.ldo + gcol;
+    if (full4) {
+      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+      if (epi == VFML_EPI_GRU_ZR && !lowhalf)
+        x0 = *reinterpret_cast<const f32x4*>(a.aux0 + (int64_t)grow * a.ld_aux0 + (gcol - a.split));
+      if (epi == VFML_EPI_GRU_Q) {
+        x0 = *reinterpret_cast<const f32x4*>(a.aux0 + (int64_t)grow * a.ld_aux0 + gcol);
+        x1 = *reinterpret_cast<const f32x4*>(a.aux1 + (int64_t)grow * a.ld_aux1 + gcol);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = epi1(v[e], epi, lowhalf, x0[e], x1[e]);
+      *reinterpret_cast<f32x4*>(o) = v;
+    } else {
+      for (int e = 0; e < 4 && gcol + e < a.cout; ++e) {
+        float x0 = 0.f, x1 = 0.f;
+        const bool lh = gcol + e < a.split;
+        if (epi == VFML_EPI_GRU_ZR && !lh) x0 = a.aux0[(int64_t)grow * a.ld_aux0 + (gcol + e - a.split)];
+        if (epi == VFML_EPI_GRU_Q) {
+          x0 = a.aux0[(int64_t)grow * a.ld_aux0 + gcol + e];
+          x1 = a.aux1[(int64_t)grow * a.ld_aux1 + gcol + e];
         }
-        a.out[(int64_t)row * a.ldo + col] = v;
+        o[e] = epi1(v[e], epi, lh, x0, x1);
       }
     }
   }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool BIGC>
 int launch(const SplitArgs& a, hipStream_t s) {
-  constexpr size_t lds = 2 * 2 * (KG * (BM + 2) + KG * (BN + 2)) * 16;
+  constexpr size_t stage = 2 * 2 * (KG * (BM + 2) + KG * (BN + 2)) * 16;
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t lds = stage > ctile ? stage : ctile;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<BN, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<BN, WM, WN, BIGC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -312,21 +405,21 @@ int launch(const SplitArgs& a, hipStream_t s) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_split_kernel<BN, WM, WN>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_split_kernel<BN, WM, WN, BIGC>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
-// f32 [rows][k] (row stride ld) -> hi/lo f16 planes [rows][kp], zero padded to kp
-__global__ void split_f16_kernel(const float* __restrict__ src, int64_t rows, int k, int ld, int kp,
+// f32 [rows][k] (row stride ld) * scale -> hi/lo f16 planes [rows][kp], zero padded to kp
+__global__ void split_f16_kernel(const float* __restrict__ src, int64_t rows, int k, int ld, int kp, float scale,
                                  _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
   const int64_t total = rows * (kp / 2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t rrow = i / (kp / 2);
     const int c = (int)(i - rrow * (kp / 2)) * 2;
-    const float a = c < k ? src[rrow * ld + c] : 0.f;
-    const float b = c + 1 < k ? src[rrow * ld + c + 1] : 0.f;
+    const float a = c < k ? src[rrow * ld + c] * scale : 0.f;
+    const float b = c + 1 < k ? src[rrow * ld + c + 1] * scale : 0.f;
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h[0]) * LO_SCALE, (b - (float)h[1]) * LO_SCALE);
+    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
     *reinterpret_cast<fp16x2*>(hi + rrow * kp + c) = h;
     *reinterpret_cast<fp16x2*>(lo + rrow * kp + c) = l;
   }
@@ -334,20 +427,22 @@ __global__ void split_f16_kernel(const float* __restrict__ src, int64_t rows, in
 
 }  // namespace
 
-extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, void* hi, void* lo, int kp,
+extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, float scale, void* hi, void* lo, int kp,
                               void* stream) {
   VFML_REQUIRE(src && hi && lo, "vfml_split_f16: null pointer");
-  VFML_REQUIRE(rows > 0 && k > 0 && ld >= k && kp >= k && kp % 8 == 0, "vfml_split_f16: bad rows/k/ld/kp (kp%%8==0)");
+  VFML_REQUIRE(rows > 0 && k > 0 && ld >= k && kp >= k && kp % 32 == 0, "vfml_split_f16: bad rows/k/ld/kp (kp%%32==0)");
+  VFML_REQUIRE(scale > 0.f, "vfml_split_f16: scale must be positive (a power of two keeps the split exact)");
   VFML_REQUIRE(vfml_aligned16(hi) && vfml_aligned16(lo), "vfml_split_f16: hi/lo must be 16-byte aligned");
   const int64_t total = rows * (kp / 2);
   int64_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(split_f16_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, rows, k,
-                     ld, kp, (_Float16*)hi, (_Float16*)lo);
+                     ld, kp, scale, (_Float16*)hi, (_Float16*)lo);
   return vfml_check_launch("vfml_split_f16");
 }
 
-extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, void* stream) {
+extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
+                                 void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
   VFML_REQUIRE(d->in0 && w_hi && w_lo && d->out, "vfml_conv2d_split: null in0/w_hi/w_lo/out");
   VFML_REQUIRE(d->c0 > 0 && d->c0 % 4 == 0 && d->ld0 % 4 == 0 && d->ld0 >= d->c0,
@@ -356,13 +451,14 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(two ? (d->c1 > 0 && d->c1 % 4 == 0 && d->ld1 % 4 == 0 && d->ld1 >= d->c1) : d->c1 == 0,
                "vfml_conv2d_split: c1=%d ld1=%d inconsistent with in1", d->c1, d->ld1);
   VFML_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "vfml_conv2d_split: empty problem");
-  VFML_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad_h >= 0 && d->pad_w >= 0,
-               "vfml_conv2d_split: bad kernel geometry");
+  VFML_REQUIRE(d->kh > 0 && d->kw > 0 && d->kh * d->kw < 64 && d->stride > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+               "vfml_conv2d_split: bad kernel geometry (kh*kw must be < 64)");
   VFML_REQUIRE(d->ldo >= d->cout, "vfml_conv2d_split: ldo=%d < cout=%d", d->ldo, d->cout);
   VFML_REQUIRE(vfml_aligned16(d->in0) && vfml_aligned16(w_hi) && vfml_aligned16(w_lo) && (!two || vfml_aligned16(d->in1)),
                "vfml_conv2d_split: in0/in1/w_hi/w_lo must be 16-byte aligned");
+  VFML_REQUIRE(w_scale > 0.f, "vfml_conv2d_split: w_scale must be the positive scale given to vfml_split_f16");
   const int K = d->kh * d->kw * (d->c0 + d->c1);
-  VFML_REQUIRE(kp >= K && kp % 8 == 0 && kp < K + 8, "vfml_conv2d_split: kp=%d must be K=%d rounded up to 8", kp, K);
+  VFML_REQUIRE(kp >= K && kp % BK == 0 && kp < K + BK, "vfml_conv2d_split: kp=%d must be K=%d rounded up to %d", kp, K, BK);
   const int ho = (d->h + 2 * d->pad_h - d->kh) / d->stride + 1;
   const int wo = (d->w + 2 * d->pad_w - d->kw) / d->stride + 1;
   VFML_REQUIRE(ho > 0 && wo > 0, "vfml_conv2d_split: empty output");
@@ -370,34 +466,50 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(M64 < (1ll << 31) - BM, "vfml_conv2d_split: too many output pixels");
   {
     const int64_t px = (int64_t)d->n * d->h * d->w + (int64_t)(d->pad_h + 1) * d->w + d->pad_w;
-    VFML_REQUIRE(px * d->ld0 < (1ll << 31) && (!two || px * d->ld1 < (1ll << 31)),
-                 "vfml_conv2d_split: a source spans >= 2^31 floats");
-    VFML_REQUIRE(((int64_t)d->cout + 128) * kp < (1ll << 31), "vfml_conv2d_split: weight planes too large");
+    VFML_REQUIRE(px * d->ld0 * 4 < (1ll << 30) && (!two || px * d->ld1 * 4 < (1ll << 30)),
+                 "vfml_conv2d_split: a source spans >= 1 GiB");
+    VFML_REQUIRE(((int64_t)d->cout + 128) * kp * 2 < (1ll << 30), "vfml_conv2d_split: weight planes too large");
   }
-  if (d->epilogue == VFML_EPI_GRU_ZR)
-    VFML_REQUIRE(d->aux0 && d->split > 0 && d->split < d->cout, "vfml_conv2d_split: GRU_ZR needs aux0 and split");
+  if (d->epilogue == VFML_EPI_GRU_ZR || d->epilogue == VFML_EPI_TANH_RELU)
+    VFML_REQUIRE(d->split > 0 && d->split < d->cout && d->split % 4 == 0,
+                 "vfml_conv2d_split: split=%d must be a multiple of 4 inside (0, cout)", d->split);
+  if (d->epilogue == VFML_EPI_GRU_ZR) VFML_REQUIRE(d->aux0, "vfml_conv2d_split: GRU_ZR needs aux0");
   if (d->epilogue == VFML_EPI_GRU_Q) VFML_REQUIRE(d->aux0 && d->aux1, "vfml_conv2d_split: GRU_Q needs aux0 and aux1");
   VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_GRU_Q, "vfml_conv2d_split: bad epilogue");
 
   SplitArgs a;
-  a.in0 = d->in0; a.in1 = two ? d->in1 : d->in0;
+  // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
+  const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;
+  const int64_t e0 = (d->in0 - base) + ((int64_t)d->n * d->h * d->w - 1) * d->ld0 + d->c0;
+  const int64_t e1 = two ? (d->in1 - base) + ((int64_t)d->n * d->h * d->w - 1) * d->ld1 + d->c1 : 0;
+  VFML_REQUIRE((e0 > e1 ? e0 : e1) * 4 < (1ll << 31),
+               "vfml_conv2d_split: in0 and in1 must be slices of one buffer (< 2 GiB apart)");
+  a.in0 = base; a.in1 = base;
+  a.d0off = (int)(d->in0 - base); a.d1off = two ? (int)(d->in1 - base) : 0;
+  a.bytes0 = (int)((e0 > e1 ? e0 : e1) * 4);
   a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo; a.bias = d->bias;
   a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
   a.c0 = d->c0; a.ld0 = d->ld0; a.c1 = d->c1; a.ld1 = two ? d->ld1 : d->ld0; a.ctot = d->c0 + d->c1;
   a.H = d->h; a.W = d->w; a.ho = ho; a.wo = wo;
-  a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.M = (int)M64; a.K = K; a.Kp = kp; a.cout = d->cout;
+  a.bytesw = (int)((int64_t)d->cout * kp * 2);
   a.ldo = d->ldo; a.ld_aux0 = d->ld_aux0; a.ld_aux1 = d->ld_aux1;
-  a.epilogue = d->epilogue; a.split = d->split; a.out_scale = d->out_scale;
+  a.epilogue = d->epilogue; a.split = (d->epilogue == VFML_EPI_GRU_ZR || d->epilogue == VFML_EPI_TANH_RELU) ? d->split : 0;
+  a.out_scale = d->out_scale; a.w_inv = 1.0f / w_scale;
   a.mtiles = (a.M + BM - 1) / BM;
+  a.vec_ok = vfml_aligned16(d->out) && d->ldo % 4 == 0 &&
+             (!d->aux0 || (vfml_aligned16(d->aux0) && d->ld_aux0 % 4 == 0)) &&
+             (!d->aux1 || (vfml_aligned16(d->aux1) && d->ld_aux1 % 4 == 0));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool bigc = a.ctot >= BK;
   if (d->cout > 64) {
     a.ntiles = (d->cout + 127) / 128;
-    return launch<128, 2, 2>(a, s);
+    return bigc ? launch<128, 2, 2, true>(a, s) : launch<128, 2, 2, false>(a, s);
   } else if (d->cout > 32) {
     a.ntiles = 1;
-    return launch<64, 2, 2>(a, s);
+    return bigc ? launch<64, 2, 2, true>(a, s) : launch<64, 2, 2, false>(a, s);
   }
   a.ntiles = 1;
-  return launch<32, 4, 1>(a, s);
+  return bigc ? launch<32, 4, 1, true>(a, s) : launch<32, 4, 1, false>(a, s);
 }

@@ -66,8 +66,8 @@ def lib():
     L.vfml_last_error.restype = c_char_p
     L.vfml_abi_version.restype = c_int
     L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
-    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]
-    L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]
+    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_void_p]
+    L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_frames_to_nhwc4.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
     L.vfml_instnorm_workspace_bytes.restype = c_int64
     L.vfml_instnorm_workspace_bytes.argtypes = [c_int, c_int, c_int]
@@ -150,16 +150,27 @@ def conv_variant(cout, split=False):
 
 
 class SplitWeight:
-    """[rows][k] f32 matrix as two f16 planes [rows][kp] (hi, lo*2^11) for vfml_conv2d_split."""
+    """[rows][k] f32 matrix (times a power-of-two `scale`) as two f16 planes [rows][kp] (hi, lo) for
+    vfml_conv2d_split."""
 
     def __init__(self, rows, k, device):
-        self.rows, self.k, self.kp = rows, k, (k + 7) // 8 * 8
+        self.rows, self.k, self.kp = rows, k, (k + 31) // 32 * 32
+        self.scale = 1.0
         self.hi = torch.empty(rows * self.kp, dtype=torch.float16, device=device)
         self.lo = torch.empty(rows * self.kp, dtype=torch.float16, device=device)
 
-    def fill(self, src, src_off=0, ld=None):
+    @staticmethod
+    def auto_scale(absmax):
+        """Largest power of two that keeps scale * absmax below 2^14 (f16 max is 65504)."""
+        import math
+        if not (absmax > 0.0) or not math.isfinite(absmax):
+            return 1.0
+        return 2.0 ** math.floor(math.log2(16384.0 / absmax))
+
+    def fill(self, src, src_off=0, ld=None, scale=1.0):
         """src: flat f32 device tensor holding [rows][k] at float offset src_off with row stride ld."""
-        _check(lib().vfml_split_f16(_ptr(_dev(src), src_off), self.rows, self.k, ld or self.k,
+        self.scale = float(scale)
+        _check(lib().vfml_split_f16(_ptr(_dev(src), src_off), self.rows, self.k, ld or self.k, self.scale,
                                     c_void_p(self.hi.data_ptr()), c_void_p(self.lo.data_ptr()), self.kp, _stream()),
                "vfml_split_f16")
         return self
@@ -187,7 +198,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         def launch():
             _check(lib().vfml_conv2d_split(ctypes.byref(d), c_void_p(weight.hi.data_ptr() + 2 * weight_off * weight.kp),
                                            c_void_p(weight.lo.data_ptr() + 2 * weight_off * weight.kp), weight.kp,
-                                           _stream()), "vfml_conv2d_split")
+                                           weight.scale, _stream()), "vfml_conv2d_split")
     else:
         def launch():
             _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")

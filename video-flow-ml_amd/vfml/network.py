@@ -97,7 +97,8 @@ class MOFNetHIP(_Holder):
             with torch.cuda.device(device):
                 for name, (wflat, b) in list(P.items()):
                     cout = b.numel()
-                    P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat), b)
+                    sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
+                    P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
         self._packed, self._packed_key = P, key
         return P
 
@@ -246,7 +247,7 @@ class MOFNetHIP(_Holder):
                     sw = self._ws.get(key)
                     if sw is None or sw.hi.device != dev:
                         sw = self._ws[key] = hip.SplitWeight(N * Sl[l], D, dev)
-                    tgt_w.append(sw.fill(fl[l]))
+                    tgt_w.append(sw.fill(fl[l], scale=16.0))      # features are O(1): keeps lo halves normal
                 w_row = lambda tgt, l: tgt * Sl[l]            # row offset into the split planes
             else:
                 tgt_w = fl
@@ -258,22 +259,24 @@ class MOFNetHIP(_Holder):
                                    in0_off=c * Pn * D, out_off=(c - 1) * Pn * ldl[l], out_scale=scale,
                                    weight_off=w_row(tgt, l))
 
-            # K2 context encoder on the centre frames -> hx[:, 0:128] = tanh, hx[:, 128:256] = relu
-            hx = self._buf("hx", MP * 512, dev)
-            self._encoder("cnet", frames[H * W * 4:], M, H, W, P, dev, hx, 512, 0, hip.EPI_TANH_RELU, self.hidden_dim)
+            # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
+            # (one allocation, so that cat([r*h, x]) and cat([h, x]) are channel slices of it)
+            GLD, Z, RH, HH, INP, MF, MT = 768, 0, 128, 256, 384, 512, 640
+            G = self._buf("gru_state", MP * GLD, dev)
+            # K2 context encoder on the centre frames -> h = tanh(first half), inp = relu(second half)
+            self._encoder("cnet", frames[H * W * 4:], M, H, W, P, dev, G, GLD, HH, hip.EPI_TANH_RELU, self.hidden_dim)
 
             corr = self._buf("corr", MP * 2 * cor_p, dev, zero=True)   # pad channels stay zero
             c1 = self._buf("c1", MP * 256, dev)
             cf = self._buf("cf", MP * 256, dev)
             f1 = self._buf("f1", MP * 128, dev)
-            zr = self._buf("zr", MP * 256, dev)
             fh = self._buf("fh", MP * 256, dev)
             flow4 = self._buf("flow4", MP * 4, dev)
             delta = self._buf("delta", MP * 4, dev)
             coords1 = self._buf("coords1", MP * 4, dev)
 
             hip.coords_init(coords1, M, h, w)
-            hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=hx, ld_b=512, flow_b_off=380)
+            hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124)
             ub = "update_block"
             for it in range(cfg.decoder_depth):
                 # K5
@@ -290,32 +293,39 @@ class MOFNetHIP(_Holder):
                 hip.conv2d(f1, 128, 128, M, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU)
                 wgt, b = P[f"{ub}.encoder.conv"]
-                hip.conv2d(cf, 256, 256, M, h, w, wgt, b, 124, 3, 3, hx, 512, out_off=256, pad_h=1, pad_w=1,
+                hip.conv2d(cf, 256, 256, M, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU)
                 # temporal stack fusion: 3x1 conv along the frame axis of the motion features
                 wgt, b = P[f"{ub}.tprop"]
-                hip.conv2d(hx, 128, 512, 1, M, Pn, wgt, b, 128, 3, 1, hx, 512, in0_off=256, out_off=384, pad_h=1,
+                hip.conv2d(G, 128, GLD, 1, M, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
                            epilogue=hip.EPI_RELU)
                 # SepConvGRU, horizontal then vertical
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, b = P[f"{ub}.gru.convzr{k}"]
-                    hip.conv2d(hx, 512, 512, M, h, w, wgt, b, 256, kh, kw, zr, 256, pad_h=kh // 2, pad_w=kw // 2,
-                               epilogue=hip.EPI_GRU_ZR, split=128, aux0=hx, ld_aux0=512)
+                    # [z | r*h] = gates(conv([h | x]))
+                    hip.conv2d(G, 512, GLD, M, h, w, wgt, b, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
+                               pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_GRU_ZR, split=128,
+                               aux0=G, ld_aux0=GLD, aux0_off=HH)
                     wgt, b = P[f"{ub}.gru.convq{k}"]
-                    hip.conv2d(zr, 128, 256, M, h, w, wgt, b, 128, kh, kw, hx, 512, in0_off=128,
-                               in1=hx, c1=384, ld1=512, in1_off=128, pad_h=kh // 2, pad_w=kw // 2,
-                               epilogue=hip.EPI_GRU_Q, aux0=zr, ld_aux0=256, aux1=hx, ld_aux1=512)
+                    # h = (1 - z) h + z tanh(conv([r*h | x])), in place
+                    hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
+                               in1=G, c1=384, ld1=GLD, in1_off=INP, pad_h=kh // 2, pad_w=kw // 2,
+                               epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
+                               aux1=G, ld_aux1=GLD, aux1_off=HH)
                 # flow head
                 wgt, b = P[f"{ub}.flow_head.conv1"]
-                hip.conv2d(hx, 128, 512, M, h, w, wgt, b, 256, 3, 3, fh, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
+                hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU)
                 wgt, b = P[f"{ub}.flow_head.conv2"]
                 hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1)
-                hip.coords_update(coords1, delta, M, h, w, flow_a=flow4, ld_a=4, flow_b=hx, ld_b=512, flow_b_off=380)
+                hip.coords_update(coords1, delta, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                                  flow_b_off=MF + 124)
 
             # mask head on the final hidden state, then K8 for every flow of the output tensor
             mask = self._buf("mask", MP * 1152, dev)
             wgt, b = P[f"{ub}.mask.0"]
-            hip.conv2d(hx, 128, 512, M, h, w, wgt, b, 256, 3, 3, fh, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
+            hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                       epilogue=hip.EPI_RELU)
             wgt, b = P[f"{ub}.mask.2"]
             hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25)
             up = torch.empty(2 * M, H, W, 2, device=dev, dtype=torch.float32)
