@@ -67,6 +67,35 @@ def test_uint8_frames_equal_float_frames(gpu):
     assert torch.equal(a, b)
 
 
+def test_sliding_window_feature_cache_is_exact(gpu):
+    """Per-frame encoder outputs reused across overlapping windows (frame_keys) give bit-identical
+    fields to encoding every window from scratch; so does the resident-clip processor path."""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.synth import synthetic_clip
+    net, _ = _pair()
+    frames = synthetic_clip(8, 128, 160)
+    clip = torch.from_numpy(np.stack(frames)).cuda()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=5)
+    proc.core.model = net
+    for i in range(8):
+        a = proc.compute_optical_flow_resident(clip, i).clone()           # cached encoders
+        net.clear_feature_cache()
+        idx = proc.window_indices(8, i)
+        b, _ = net.forward_u8(clip[idx])                                   # everything recomputed
+        assert torch.equal(a, b[0, 3].permute(1, 2, 0)), i
+        c = proc.compute_optical_flow(frames, i)                           # the reference API path (host floats)
+        assert np.array_equal(a.cpu().numpy(), c), i
+    # tiles: a different crop of the same frame is a different cache entry
+    tile = {'x': 32, 'y': 0, 'width': 128, 'height': 128}
+    t1 = proc.compute_optical_flow_resident(clip, 3, tile=tile).clone()
+    t2, _ = net.forward_u8(clip[proc.window_indices(8, 3)][:, 0:128, 32:160].contiguous())
+    assert torch.equal(t1, t2[0, 3].permute(1, 2, 0))
+
+
 def test_engine_refuses_cpu_tensors():
     from vfml import build_network, get_cfg
     net = build_network(get_cfg())

@@ -136,14 +136,19 @@ class VideoFlowProcessor:
         Same window, same /255, same network and index pick as compute_optical_flow; the u8->float
         conversion runs inside the engine's first kernel."""
         self._require_model()
-        idx = torch.tensor(self.window_indices(clip.shape[0], frame_idx), device=clip.device)
-        win = clip.index_select(0, idx)
+        frame_ids = self.window_indices(clip.shape[0], frame_idx)
+        win = clip.index_select(0, torch.tensor(frame_ids, device=clip.device))
+        rect = None
         if tile is not None:
+            rect = (tile['x'], tile['y'], tile['width'], tile['height'])
             win = win[:, tile['y']:tile['y'] + tile['height'], tile['x']:tile['x'] + tile['width']]
         H, W = win.shape[1:3]
         model = self.core.model
         if H % 8 == 0 and W % 8 == 0 and hasattr(model, "forward_u8"):
-            flows, _ = model.forward_u8(win, return_lowres=False)
+            # a frame of this clip (and tile) is the same pixels in every window that contains it:
+            # let the engine reuse its per-frame encoder outputs across the sliding windows
+            keys = [(clip.data_ptr(), clip._version, i, rect) for i in frame_ids]
+            flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=keys)
             return flows[0, flows.shape[1] // 2].permute(1, 2, 0)
         batch = (win.float() / 255.0).permute(0, 3, 1, 2).unsqueeze(0)
         return self.core.compute_flow_from_tensor(batch).permute(1, 2, 0)

@@ -54,7 +54,10 @@ class MOFNetHIP(_Holder):
             leaf.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
         self._packed = None
         self._packed_key = None
+        self._packed_serial = 0
         self._ws = {}
+        import collections
+        self._feat_cache = collections.OrderedDict()
 
     # ------------------------------------------------------------------ weights
     def _param(self, name):
@@ -100,6 +103,8 @@ class MOFNetHIP(_Holder):
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
                     P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
         self._packed, self._packed_key = P, key
+        self._packed_serial += 1          # new weights: cached encoder outputs are stale
+        self._feat_cache.clear()
         return P
 
     def _precision(self):
@@ -119,6 +124,7 @@ class MOFNetHIP(_Holder):
 
     def release_workspace(self):
         self._ws.clear()
+        self._feat_cache.clear()
 
     # ------------------------------------------------------------------ encoder
     def _encoder(self, prefix, x, n, H, W, P, dev, out, ldo, out_off, epilogue, split):
@@ -189,15 +195,101 @@ class MOFNetHIP(_Holder):
         return self._run(src.contiguous(), src.shape[0], src.shape[2], src.shape[3], return_lowres)
 
     @torch.no_grad()
-    def forward_u8(self, frames, return_lowres=True):
+    def forward_u8(self, frames, return_lowres=True, frame_keys=None):
         """frames: uint8 [N, H, W, 3] RGB on the GPU; /255 happens in the K1 kernel (same fp32 ops
-        as the reference's host-side conversion), saving the 4x larger float upload."""
+        as the reference's host-side conversion), saving the 4x larger float upload.
+
+        frame_keys: optional list of N hashable ids, one per frame.  The encoders act on each frame
+        independently (instance norm is per image), so their outputs depend on the frame alone:
+        with keys the engine keeps the per-frame feature maps, pooled target pyramids and context
+        maps of recently seen frames and encodes only the frames it has not seen - in a sliding
+        window that is 1 of N.  The caller promises that equal keys mean equal pixels."""
         if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8
                 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 [N,H,W,3] device tensor")
-        return self._run(frames.contiguous(), frames.shape[0], frames.shape[1], frames.shape[2], return_lowres)
+        if frame_keys is not None and len(frame_keys) != frames.shape[0]:
+            raise ValueError("frame_keys must have one entry per frame")
+        return self._run(frames.contiguous(), frames.shape[0], frames.shape[1], frames.shape[2], return_lowres,
+                         frame_keys)
 
-    def _run(self, src, N, H, W, return_lowres):
+    # ------------------------------------------------------------------ per-frame encoder cache
+    FEATURE_CACHE_FRAMES = 12
+
+    def clear_feature_cache(self):
+        self._feat_cache.clear()
+
+    def _cache_get(self, kind, key):
+        ent = self._feat_cache.get((kind, key))
+        if ent is not None:
+            self._feat_cache.move_to_end((kind, key))
+        return ent
+
+    def _cache_put(self, kind, key, value):
+        self._feat_cache[(kind, key)] = value
+        while sum(1 for k in self._feat_cache if k[0] == kind) > self.FEATURE_CACHE_FRAMES:
+            oldest = next(k for k in self._feat_cache if k[0] == kind)
+            del self._feat_cache[oldest]
+
+    def _frame_features(self, src, sel, keys, H, W, P, dev, L, hl, wl, Sl):
+        """Feature map + target pyramid of frames `sel` of the window.
+        Returns {j: (fmap [Pn*256] f32, [target operand per level])}."""
+        D = self.cfg.feat_dim
+        split = self._precision() == "f16x3"
+        out, todo = {}, []
+        for j in sel:
+            ent = self._cache_get("f", keys[j]) if keys is not None else None
+            if ent is not None:
+                out[j] = ent
+            else:
+                todo.append(j)
+        if todo:
+            m, Pn = len(todo), hl[0] * wl[0]
+            frames = self._buf("frames", m * H * W * 4, dev)
+            sub = src if m == src.shape[0] else src.index_select(0, torch.tensor(todo, device=dev))
+            hip.frames_to_nhwc4(sub.contiguous(), m, H, W, float(self.cfg.input_scale), float(self.cfg.input_shift),
+                                frames)
+            fmap = torch.empty(m * Pn * D, device=dev)          # owned by the cache entries (views)
+            self._encoder("fnet", frames, m, H, W, P, dev, fmap, D, 0, hip.EPI_NONE, 0)
+            levels = [fmap]
+            for l in range(1, L):
+                t = torch.empty(m * Sl[l] * D, device=dev)
+                hip.avgpool2x2(levels[-1], m, hl[l - 1], wl[l - 1], D, t)
+                levels.append(t)
+            for i, j in enumerate(todo):
+                tg = []
+                for l in range(L):
+                    f = levels[l][i * Sl[l] * D:(i + 1) * Sl[l] * D]
+                    # features are O(1): x16 keeps the lo halves of the split normal
+                    tg.append(hip.SplitWeight(Sl[l], D, dev).fill(f, scale=16.0) if split else f)
+                ent = (fmap[i * Pn * D:(i + 1) * Pn * D], tg)
+                out[j] = ent
+                if keys is not None:
+                    self._cache_put("f", keys[j], ent)
+        return out
+
+    def _frame_context(self, src, sel, keys, H, W, P, dev, Pn):
+        """Context maps (tanh | relu halves, [Pn*256] f32) of frames `sel`."""
+        out, todo = {}, []
+        for j in sel:
+            ent = self._cache_get("c", keys[j]) if keys is not None else None
+            if ent is not None:
+                out[j] = ent
+            else:
+                todo.append(j)
+        if todo:
+            m = len(todo)
+            frames = self._buf("frames", m * H * W * 4, dev)
+            hip.frames_to_nhwc4(src.index_select(0, torch.tensor(todo, device=dev)).contiguous(), m, H, W,
+                                float(self.cfg.input_scale), float(self.cfg.input_shift), frames)
+            ctx = torch.empty(m * Pn * 256, device=dev)
+            self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim)
+            for i, j in enumerate(todo):
+                out[j] = ctx[i * Pn * 256:(i + 1) * Pn * 256]
+                if keys is not None:
+                    self._cache_put("c", keys[j], out[j])
+        return out
+
+    def _run(self, src, N, H, W, return_lowres, frame_keys=None):
         cfg = self.cfg
         if N < 3:
             raise ValueError(f"need at least 3 frames, got {N}")
@@ -217,54 +309,38 @@ class MOFNetHIP(_Holder):
         cor_p = (cor + 3) // 4 * 4   # per-direction channel block, 16-byte aligned
 
         with torch.cuda.device(dev):
-            # K1
-            frames = self._buf("frames", N * H * W * 4, dev)
-            hip.frames_to_nhwc4(src, N, H, W, float(cfg.input_scale), float(cfg.input_shift), frames)
-
-            # K2 feature encoder on all N frames
-            fmap = self._buf("fmap", N * Pn * D, dev)
-            self._encoder("fnet", frames, N, H, W, P, dev, fmap, D, 0, hip.EPI_NONE, 0)
-
-            # target-feature pyramid (levels 1..L-1), all frames
             hl, wl = [h], [w]
-            fl = [fmap]
             for l in range(1, L):
                 hl.append(hl[-1] // 2)
                 wl.append(wl[-1] // 2)
-                t = self._buf(f"fmap_l{l}", N * hl[l] * wl[l] * D, dev)
-                hip.avgpool2x2(fl[-1], N, hl[l - 1], wl[l - 1], D, t)
-                fl.append(t)
             Sl = [hl[l] * wl[l] for l in range(L)]
             ldl = [(s + 31) // 32 * 32 for s in Sl]
+            keys = None
+            if frame_keys is not None:   # geometry and arithmetic are part of a cached frame's identity
+                keys = [(k, H, W, L, self._precision(), self._packed_serial) for k in frame_keys]
 
-            # K3/K4 correlation pyramids: rows = (centre frame, query cell)
+            # K1 + K2: feature maps and pooled target pyramids, per frame (cached across windows)
+            feats = self._frame_features(src, list(range(N)), keys, H, W, P, dev, L, hl, wl, Sl)
+
+            # K3/K4 correlation pyramids: rows = (centre frame, query cell); level l is one GEMM of the
+            # centre frame's features against the 2^l-pooled features of the neighbour frame
             pyr = {d: [self._buf(f"pyr_{d}{l}", MP * ldl[l], dev) for l in range(L)] for d in ("f", "b")}
             scale = 1.0 / float(D) ** 0.5
-            if self._precision() == "f16x3":
-                tgt_w = []
-                for l in range(L):
-                    key = ("tgt_split", l, N * Sl[l])
-                    sw = self._ws.get(key)
-                    if sw is None or sw.hi.device != dev:
-                        sw = self._ws[key] = hip.SplitWeight(N * Sl[l], D, dev)
-                    tgt_w.append(sw.fill(fl[l], scale=16.0))      # features are O(1): keeps lo halves normal
-                w_row = lambda tgt, l: tgt * Sl[l]            # row offset into the split planes
-            else:
-                tgt_w = fl
-                w_row = lambda tgt, l: tgt * Sl[l] * D        # float offset into the f32 features
             for c in range(1, N - 1):
                 for d, tgt in (("f", c + 1), ("b", c - 1)):
                     for l in range(L):
-                        hip.conv2d(fmap, D, D, 1, 1, Pn, tgt_w[l], None, Sl[l], 1, 1, pyr[d][l], ldl[l],
-                                   in0_off=c * Pn * D, out_off=(c - 1) * Pn * ldl[l], out_scale=scale,
-                                   weight_off=w_row(tgt, l))
+                        hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[d][l],
+                                   ldl[l], out_off=(c - 1) * Pn * ldl[l], out_scale=scale)
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
             # (one allocation, so that cat([r*h, x]) and cat([h, x]) are channel slices of it)
             GLD, Z, RH, HH, INP, MF, MT = 768, 0, 128, 256, 384, 512, 640
             G = self._buf("gru_state", MP * GLD, dev)
             # K2 context encoder on the centre frames -> h = tanh(first half), inp = relu(second half)
-            self._encoder("cnet", frames[H * W * 4:], M, H, W, P, dev, G, GLD, HH, hip.EPI_TANH_RELU, self.hidden_dim)
+            ctx = self._frame_context(src, list(range(1, N - 1)), keys, H, W, P, dev, Pn)
+            Gv = G.view(MP, GLD)
+            for c in range(1, N - 1):
+                Gv[(c - 1) * Pn:c * Pn, HH:HH + 256].copy_(ctx[c].view(Pn, 256))
 
             corr = self._buf("corr", MP * 2 * cor_p, dev, zero=True)   # pad channels stay zero
             c1 = self._buf("c1", MP * 256, dev)
