@@ -47,8 +47,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--seq", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-height", type=int, default=0,
-                    help="CPU-baseline sample: full frame if 0, else a centre crop of this height (16:9)")
+    ap.add_argument("--cpu-sample-height", type=int, default=544,
+                    help="CPU-baseline sample: 0 = one full-size field (minutes of CPU time), else one field on a "
+                         "centre crop of this height (16:9), scaled to full size by the analytic FLOP ratio")
     args = ap.parse_args()
 
     from vfml import dist as vdist, get_cfg, hip
@@ -166,41 +167,49 @@ def main():
 
 
 def cpu_baseline(args, proc, clip_np, field_idx, engine_field, T):
-    """One flow field of the workload on the host cores with the CPU oracle; also the EPE between
-    that field and the engine's (the same window, the same seeded weights)."""
+    """The CPU oracle (fp32 PyTorch restatement) on the host cores, on a bounded sample of the
+    workload: one field of the same clip/window/weights, by default on a 960x544 centre crop, scaled
+    to a full-size field by the analytic FLOP ratio (vfml/flops.py; correlation is quadratic in area,
+    convolutions linear).  Also returns the engine-vs-oracle end-point error on that sample."""
     from oracle import mof_oracle as mo
+    from vfml.flops import field_work
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    depth = proc.core.cfg.decoder_depth
     ocfg = mo.get_cfg()
-    ocfg.decoder_depth = proc.core.cfg.decoder_depth
+    ocfg.decoder_depth = depth
     ora = mo.build_network(ocfg).eval()
     ora.load_state_dict({k: v.cpu() for k, v in proc.core.model.state_dict().items()})
     idx = proc.window_indices(len(clip_np), field_idx)
     win = np.stack([clip_np[i] for i in idx])
     H, W = win.shape[1:3]
-    y0 = x0 = 0
-    if args.cpu_sample_height and args.cpu_sample_height < H:
+    full = not (args.cpu_sample_height and args.cpu_sample_height < H)
+    if not full:
         h = args.cpu_sample_height // 8 * 8
         w = min(W, (h * 16 // 9) // 8 * 8)
         y0, x0 = (H - h) // 2 // 8 * 8, (W - w) // 2 // 8 * 8
-        win = win[:, y0:y0 + h, x0:x0 + w]
+        win = np.ascontiguousarray(win[:, y0:y0 + h, x0:x0 + w])
     x = torch.from_numpy(win.astype(np.float32) / 255.0).permute(0, 3, 1, 2)[None]
     t0 = time.perf_counter()
     flows, _ = ora(x, {})
     dt = time.perf_counter() - t0
     ref = flows[0, flows.shape[1] // 2].permute(1, 2, 0)
-    full = win.shape[1] == H and win.shape[2] == W
-    out = {"value": 1.0 / dt, "unit": "flow-fields/s", "cores": cores, "kind": "port",
-           "seconds": dt, "threads": torch.get_num_threads()}
     if full:
-        epe = (engine_field.cpu() - ref).pow(2).sum(-1).sqrt()
-        out["sample"] = f"1 full {W}x{H} seq{T} field (field {field_idx} of the clip), fp32 PyTorch CPU oracle"
-        out["epe_mean_px"] = float(epe.mean())
-        out["epe_max_px"] = float(epe.max())
+        got = engine_field.cpu()
+        ratio = 1.0
+        sample = f"1 full {W}x{H} seq{T} field (field {field_idx} of the clip)"
     else:
-        out["sample"] = (f"1 field on a {win.shape[2]}x{win.shape[1]} centre crop of the {W}x{H} clip; "
-                         f"value is per cropped field (NOT area-scaled: correlation cost is quadratic in area)")
-    return out
+        eng, _ = proc.core.model.forward_u8(torch.from_numpy(win).to(engine_field.device), return_lowres=False)
+        got = eng[0, eng.shape[1] // 2].permute(1, 2, 0).cpu()
+        ratio = field_work(H, W, T, depth)["total_flops"] / field_work(win.shape[1], win.shape[2], T, depth)["total_flops"]
+        sample = (f"1 field on the {win.shape[2]}x{win.shape[1]} centre crop of the window of field {field_idx} "
+                  f"({dt:.1f} s), scaled to {W}x{H} by the analytic FLOP ratio {ratio:.2f}")
+    epe = (got - ref).pow(2).sum(-1).sqrt()
+    return {"value": 1.0 / (dt * ratio), "unit": "flow-fields/s", "cores": cores, "kind": "port",
+            "sample": sample + ", fp32 PyTorch CPU oracle (oracle/mof_oracle.py), all host threads",
+            "sample_seconds": dt, "flop_ratio_to_full": ratio, "threads": torch.get_num_threads(),
+            "epe_mean_px": float(epe.mean()), "epe_max_px": float(epe.max()),
+            "epe_note": "engine vs oracle on the same sample, same seeded weights; tolerance 1e-3 px mean"}
 
 
 if __name__ == "__main__":

@@ -207,6 +207,27 @@ def main():
     z = np.load(os.path.join(d, "flow_frame_000001_lod2.npz"))
     J["lod_members"] = {k: {"dtype": str(z[k].dtype), "shape": list(z[k].shape)} for k in z.files}
 
+    # ---- CLI flag surface (flow_processor.py:1272-1332): names, defaults, choices — read from the
+    # parser definition with the ast module (the file itself needs cv2 to import)
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "flow_processor.py")).read())
+    flags = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument" and node.args:
+            name = ast.literal_eval(node.args[0])
+            kw = {k.arg: k.value for k in node.keywords}
+            ent = {}
+            if "default" in kw:
+                ent["default"] = ast.literal_eval(kw["default"])
+            if "choices" in kw:
+                ent["choices"] = ast.literal_eval(kw["choices"])
+            if "action" in kw:
+                ent["action"] = ast.literal_eval(kw["action"])
+            if "type" in kw:
+                ent["type"] = kw["type"].id
+            flags[name] = ent
+    J["cli_flags"] = flags
+
     with open(os.path.join(HERE, "host_plumbing.json"), "w") as f:
         json.dump(J, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "host_plumbing.npz"), **A)

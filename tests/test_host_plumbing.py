@@ -227,3 +227,57 @@ def test_device_manager_contract(monkeypatch):
     assert dm.get_device("cuda") == "cpu" and dm.get_device_info() == {"device": "cpu", "cuda_available": False}
     dm.reset()
     assert dm.get_device("auto") == "cpu"
+
+
+def test_cli_flags_match_reference():
+    """Same flag names, defaults, choices and kinds as the reference parser (flow_processor.py:1272-1332)."""
+    import flow_processor
+    parser = flow_processor.build_parser()
+    ours = {}
+    for a in parser._actions:
+        if not a.option_strings or a.option_strings[0] == "-h":
+            continue
+        ent = {}
+        if a.default is not None or a.option_strings[0] in ("--start-time", "--duration", "--flow-input", "--save-flow",
+                                                            "--use-flow-cache", "--model-path"):
+            ent["default"] = a.default
+        if a.choices is not None:
+            ent["choices"] = list(a.choices)
+        if a.nargs == 0:
+            ent["action"] = "store_true"
+            ent.pop("default", None)
+        if a.type is not None:
+            ent["type"] = a.type.__name__
+        ours[a.option_strings[0]] = ent
+    assert ours == J["cli_flags"]
+
+
+def test_cli_fills_cache_with_injected_cpu_model(tmp_path, monkeypatch):
+    """flow_processor.py end to end on CPU (synthetic input, stand-in model): cache directory name,
+    one .npz per frame, LOD files, second run is a cache hit."""
+    import flow_processor
+    import processing.videoflow_core as core_mod
+    from vfml import get_cfg
+    from vfml.weights import write_seeded_checkpoint
+    write_seeded_checkpoint(str(tmp_path), get_cfg(), seed=0)
+    monkeypatch.chdir(tmp_path)
+
+    class Net(FakeModel):
+        def load_state_dict(self, sd, strict=True):
+            return None
+
+    monkeypatch.setattr(core_mod, "build_network", lambda cfg: Net())
+    argv = ["--input", "synthetic:64x48x5", "--output", str(tmp_path / "out"), "--device", "cpu", "--sequence-length",
+            "3", "--interactive"]
+    with quiet():
+        assert flow_processor.main(argv) == 0
+    cache = tmp_path / "out" / "synthetic_64x48x5_flow_cache_videoflow_mof_sintel_standard_seq3_start0_frames5"
+    names = sorted(os.listdir(cache))
+    assert [n for n in names if "lod" not in n] == [f"flow_frame_{i:06d}.npz" for i in range(5)]
+    assert len([n for n in names if "lod" in n]) == 25
+    z = np.load(cache / "flow_frame_000002.npz")
+    assert z["flow"].shape == (48, 64, 2) and int(z["frame_idx"]) == 2
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        assert flow_processor.main(argv) == 0
+    assert "nothing to compute" in out.getvalue()

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""flow_processor.py — command line of the drop-in, flow-field part.
+
+Same flags as the reference CLI (flow_processor.py:1272-1332) and the same flow-cache contract
+(cache directory name, flow_frame_%06d.npz members, completeness check, optional LODs), with the
+frame loop of its cache-filling paths (:959-976 normal mode, :1460-1470 --interactive) running on
+the MI355X engine and, under `python -m torch.distributed.run --nproc-per-node N flow_processor.py …`,
+sharded over N GPUs with one RCCL gather (vfml.runner).
+
+Out of scope here: decoding/encoding video with OpenCV, flow visualisation encoders,
+TAA, the side-by-side composer and the Tk/Qt tools; flags that only concern those are accepted and
+reported as skipped.  Inputs: a `.npy` file holding uint8 frames [F,H,W,3]; `synthetic:WxHxF`
+(vfml.synth); or any video file when OpenCV is importable.
+"""
+import argparse
+import os
+import sys
+import time
+
+script_dir = os.path.dirname(os.path.abspath(__file__))
+if script_dir not in sys.path:
+    sys.path.insert(0, script_dir)
+
+import numpy as np
+import torch
+
+from config import DeviceManager
+from processing.flow_inference import VideoFlowInference
+from storage import FlowCacheManager
+from vfml import dist as vdist
+from vfml.runner import run_sharded
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='VideoFlow Optical Flow Processor (MI355X engine)')
+    p.add_argument('--input', default='big_buck_bunny_720p_h264.mov', help='Input video (.npy frames, synthetic:WxHxF, or a video file)')
+    p.add_argument('--output', default='results', help='Output directory')
+    p.add_argument('--device', default='auto', choices=['auto', 'cuda', 'cpu'])
+    p.add_argument('--frames', type=int, default=1000, help='Maximum number of frames to process')
+    p.add_argument('--start-frame', type=int, default=0)
+    p.add_argument('--start-time', type=float, default=None)
+    p.add_argument('--duration', type=float, default=None)
+    p.add_argument('--fast', action='store_true', help='Fast mode (depth 6, 3 levels, radius 3)')
+    p.add_argument('--flow-only', action='store_true')
+    p.add_argument('--taa', action='store_true')
+    p.add_argument('--flow-input', type=str, default=None)
+    p.add_argument('--flow-format', choices=['gamedev', 'hsv', 'torchvision', 'motion-vectors-rg8', 'motion-vectors-rgb8'],
+                   default='gamedev')
+    p.add_argument('--motion-vectors-clamp-range', type=float, default=32.0)
+    p.add_argument('--tile', action='store_true', help='1280x1280 tile mode')
+    p.add_argument('--sequence-length', type=int, default=5)
+    p.add_argument('--save-flow', choices=['flo', 'npz', 'both'], default=None)
+    p.add_argument('--force-recompute', action='store_true')
+    p.add_argument('--use-flow-cache', type=str, default=None)
+    p.add_argument('--interactive', action='store_true')
+    p.add_argument('--show-tiles', action='store_true')
+    p.add_argument('--no-autoplay', action='store_true')
+    p.add_argument('--skip-lods', action='store_true')
+    p.add_argument('--uncompressed', action='store_true')
+    p.add_argument('--model', choices=['videoflow', 'memflow'], default='videoflow')
+    p.add_argument('--model-path', type=str, default=None)
+    p.add_argument('--stage', choices=['sintel', 'things', 'kitti'], default='sintel')
+    p.add_argument('--vf-dataset', choices=['sintel', 'things', 'kitti'], default='sintel')
+    p.add_argument('--vf-architecture', choices=['mof', 'bof'], default='mof')
+    p.add_argument('--vf-variant', choices=['standard', 'noise'], default='standard')
+    return p
+
+
+def load_frames(spec, start_frame, max_frames, fps_default=30.0):
+    """-> (frames list of uint8 [H,W,3], fps, width, height, start_frame): the 5-tuple shape of the
+    reference's FrameExtractor.extract_frames (video/frame_extractor.py:139)."""
+    if spec.startswith('synthetic:'):
+        from vfml.synth import synthetic_clip
+        w, h, n = (int(v) for v in spec.split(':', 1)[1].lower().split('x'))
+        frames = synthetic_clip(n, h, w)[start_frame:start_frame + max_frames]
+    elif spec.endswith('.npy'):
+        arr = np.load(spec, mmap_mode='r')
+        if arr.ndim != 4 or arr.shape[3] != 3 or arr.dtype != np.uint8:
+            raise ValueError(f"{spec}: expected uint8 [F,H,W,3], got {arr.dtype} {arr.shape}")
+        frames = [np.ascontiguousarray(f) for f in arr[start_frame:start_frame + max_frames]]
+    else:
+        try:
+            import cv2
+        except ImportError:
+            raise SystemExit(f"Cannot decode {spec}: OpenCV is not installed. Use a .npy frame stack or synthetic:WxHxF.")
+        cap = cv2.VideoCapture(spec)
+        fps_default = cap.get(cv2.CAP_PROP_FPS) or fps_default
+        cap.set(cv2.CAP_PROP_POS_FRAMES, start_frame)
+        frames = []
+        while len(frames) < max_frames:
+            ok, bgr = cap.read()
+            if not ok:
+                break
+            frames.append(cv2.cvtColor(bgr, cv2.COLOR_BGR2RGB))
+        cap.release()
+    if not frames:
+        raise SystemExit(f"No frames read from {spec}")
+    h, w = frames[0].shape[:2]
+    return frames, fps_default, w, h, start_frame
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    rank, local_rank, world = vdist.init_distributed()
+    log = print if rank == 0 else (lambda *a, **k: None)
+
+    if args.model != 'videoflow':
+        raise SystemExit("--model memflow is not built in this round (DESIGN.md, out of scope); use --model videoflow")
+    for flag, on in (("--taa", args.taa), ("--show-tiles", args.show_tiles), ("--flow-input", args.flow_input)):
+        if on:
+            log(f"note: {flag} concerns video composition / visualisation, which this build does not do; ignored")
+    if not (args.input.startswith('synthetic:') or os.path.exists(args.input)):
+        log(f"Error: Input video not found: {args.input}")
+        return 1
+
+    device = DeviceManager().get_device(args.device)
+    if device == 'cuda' and world > 1:
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
+    frames, fps, width, height, start = load_frames(args.input, args.start_frame, args.frames)
+    n = len(frames)
+    mgr = FlowCacheManager()
+    cache_src = args.input if not args.input.startswith('synthetic:') else os.path.join(args.output, args.input.replace(':', '_') + ".npy")
+    cache_dir = args.use_flow_cache or mgr.generate_cache_path(cache_src, start, n, args.sequence_length, args.fast,
+                                                               args.tile, 'videoflow', args.vf_dataset,
+                                                               args.vf_architecture, args.vf_variant)
+    complete, fmt, missing = mgr.check_cache_exists(cache_dir, n)
+    if complete and not args.force_recompute:
+        log(f"Flow cache complete ({fmt}), nothing to compute: {cache_dir}")
+        return 0
+
+    eng = VideoFlowInference(device, args.fast, args.tile, args.sequence_length, args.vf_dataset,
+                             args.vf_architecture, args.vf_variant)
+    eng.load_model()
+    proc = eng.get_processor()
+    clip = proc.upload_clip(frames)
+    t0 = time.time()
+    flows = run_sharded(proc, clip, range(n), tile_mode=args.tile, rank=rank, world=world)
+    if str(device).startswith('cuda'):
+        torch.cuda.synchronize()
+    dt = time.time() - t0
+    if rank == 0:
+        log(f"{n} flow fields ({width}x{height}, seq {args.sequence_length}) in {dt:.2f} s = {n / dt:.2f} fields/s "
+            f"on {world} GPU(s)")
+        save_format = args.save_flow or 'npz'
+        for i in range(n):
+            mgr.save_flow_to_cache(flows[i], cache_dir, i, save_format)
+        log(f"Flow cache written: {cache_dir}")
+        if not args.skip_lods and save_format in ('npz', 'both'):
+            mgr.generate_lods_for_cache(cache_dir, n)
+        if not args.interactive:
+            log("note: video encoding / composition is out of scope for this build; the flow cache is the output")
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,57 @@
+"""Sharded flow-field job: the loop of reference flow_processor.py:959-976 / :1460-1470
+(`for i in frames: compute_optical_flow[_tiled]`) spread over the GPUs of one node.
+
+Work items are (frame) or (frame, tile); ranks take contiguous blocks (vfml.dist.shard_bounds), keep
+the clip resident in their own HBM, compute with no data-path communication, and one gather brings
+the finished fields to rank 0, which pastes tiles with the reference's hard seams
+(processing/videoflow_processor.py:277) and owns the cache files."""
+import numpy as np
+import torch
+
+from . import dist as vdist
+
+
+def _tiles(proc, width, height, tile_mode):
+    return proc.calculate_tile_grid(width, height)[4] if tile_mode else [None]
+
+
+def item_numel(height, width, tile):
+    h, w = (height, width) if tile is None else (tile['height'], tile['width'])
+    return h * w * 2
+
+
+def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None):
+    """Compute the flow field of every frame in `frame_indices` of the device-resident uint8 clip
+    [F,H,W,3].  Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2]; None elsewhere."""
+    frame_indices = list(frame_indices)
+    F, H, W = clip.shape[0], clip.shape[1], clip.shape[2]
+    tiles = _tiles(proc, W, H, tile_mode)
+    items = vdist.work_items(frame_indices, len(tiles))
+    bounds = [vdist.shard_bounds(len(items), r, world) for r in range(world)]
+    sizes = [sum(item_numel(H, W, tiles[t]) for _, t in items[lo:hi]) for lo, hi in bounds]
+    lo, hi = bounds[rank]
+    local = torch.empty(sizes[rank], dtype=torch.float32, device=clip.device)
+    off = 0
+    for f, t in items[lo:hi]:
+        flow = proc.compute_optical_flow_resident(clip, f, tile=tiles[t])
+        n = flow.numel()
+        local[off:off + n].copy_(flow.reshape(-1))
+        off += n
+    parts = vdist.gather_to_rank0(local, sizes, group=group)
+    if rank != 0:
+        return None
+    out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32)
+    slot = {f: k for k, f in enumerate(frame_indices)}
+    for (blo, bhi), part in zip(bounds, parts):
+        host = part.cpu().numpy()
+        off = 0
+        for f, t in items[blo:bhi]:
+            tile = tiles[t]
+            n = item_numel(H, W, tile)
+            if tile is None:
+                out[slot[f]] = host[off:off + n].reshape(H, W, 2)
+            else:
+                y, x, th, tw = tile['y'], tile['x'], tile['height'], tile['width']
+                out[slot[f], y:y + th, x:x + tw] = host[off:off + n].reshape(th, tw, 2)
+            off += n
+    return out
