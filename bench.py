@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--seq", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads for the CPU baseline (0 = this process's CPU share: affinity / cgroup quota, "
+                         "capped at 16 - the per-GPU share of the pool's boxes)")
     ap.add_argument("--cpu-sample-height", type=int, default=544,
                     help="CPU-baseline sample: 0 = one full-size field (minutes of CPU time), else one field on a "
                          "centre crop of this height (16:9), scaled to full size by the analytic FLOP ratio")
@@ -166,6 +169,23 @@ def main():
     print(json.dumps(result))
 
 
+def host_cpu_share(cap=16):
+    """CPUs this process may actually use: scheduler affinity, cgroup-v2 quota, capped (os.cpu_count()
+    reports the whole host, and oversubscribing a 16-CPU share with 100+ threads is far slower)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(args, proc, clip_np, field_idx, engine_field, T):
     """The CPU oracle (fp32 PyTorch restatement) on the host cores, on a bounded sample of the
     workload: one field of the same clip/window/weights, by default on a 960x544 centre crop, scaled
@@ -173,7 +193,7 @@ def cpu_baseline(args, proc, clip_np, field_idx, engine_field, T):
     convolutions linear).  Also returns the engine-vs-oracle end-point error on that sample."""
     from oracle import mof_oracle as mo
     from vfml.flops import field_work
-    cores = os.cpu_count() or 1
+    cores = args.cpu_threads or host_cpu_share()
     torch.set_num_threads(cores)
     depth = proc.core.cfg.decoder_depth
     ocfg = mo.get_cfg()

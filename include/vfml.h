@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 1
+#define VFML_ABI_VERSION 2
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + bias[c]). */
 enum {
@@ -38,6 +38,16 @@ enum {
   VFML_EPI_GRU_ZR = 5,     /* c <  split: sigmoid(v) else sigmoid(v) * aux0[p][c - split]    */
   VFML_EPI_GRU_Q = 6,      /* out = (1 - z) * h + z * tanh(v), z = aux0[p][c], h = aux1[p][c] */
 };
+
+/* Activation storage formats.
+ *   VFML_FMT_F32  plain NHWC float32.
+ *   VFML_FMT_S16  "split rows": same addressing and the same 4 bytes per channel, but every group of
+ *                 8 channels (32 bytes, a "unit") holds 8 f16 hi halves then 8 f16 lo halves with
+ *                 x = hi + lo (hi = f16(x) toward zero, lo = f16(x - hi)): the operand format of the
+ *                 split-f16 MFMA kernel, written once by the producer instead of being re-derived by
+ *                 every consumer.  Channel offsets / counts / ld are multiples of 8 (a producer may
+ *                 write a 4-channel half unit), bases 32-byte aligned. */
+enum { VFML_FMT_F32 = 0, VFML_FMT_S16 = 1 };
 
 /* Implicit-GEMM 2-D convolution / plain GEMM on the f32 matrix cores.
  *   out[p][co] = epi( sum_{ky,kx,ci} in(p; ky,kx)[ci] * w[co][ky][kx][ci] + bias[co] )
@@ -67,7 +77,11 @@ int vfml_conv2d(const vfml_conv_desc* d, void* stream);
  * of 32; the kernel divides the accumulator by w_scale.  Activations stay fp32 in HBM and are split
  * while staged into LDS. */
 int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
-                      void* stream);
+                      int in_fmt, int out_fmt, int aux_fmt, void* stream);
+/* in_fmt: format of in0/in1; out_fmt: of out; aux_fmt: of aux0/aux1 (VFML_FMT_*). */
+
+/* f32 rows [rows][c] (row stride ld_src floats) -> split rows [rows][ld_dst] (VFML_FMT_S16); c % 4 == 0. */
+int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream);
 
 /* y = scale * src (f32 [rows][k], row stride ld floats) -> hi = f16(y), lo = f16(y - hi), each
  * [rows][kp], zero padded from k to kp (kp % 32 == 0).  A power-of-two scale that brings max|y|
@@ -107,13 +121,17 @@ int vfml_avgpool2x2(const float* x, int n, int h, int w, int c, float* out, void
  * Replaces: F.grid_sample(align_corners=True) x levels. */
 int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl,
                      const int32_t* ld, int levels, int radius, int nq,
-                     const float* coords, int ld_coords, float* out, int ld_out, void* stream);
+                     const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, void* stream);
+/* out_fmt VFML_FMT_S16: channels are written as split rows; the channel count is rounded up to a
+ * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0). */
 
 /* coords1 += delta (4 floats per pixel: fwd x,y, bwd x,y); flow = coords1 - grid is written to
  * flow_a[p*ld_a..+4] and flow_b[p*ld_b..+4] (either may be NULL).  h,w give the pixel grid,
  * n maps. delta may be NULL (just (re)emit flow).  */
 int vfml_coords_update(float* coords1, const float* delta, int n, int h, int w,
-                       float* flow_a, int ld_a, float* flow_b, int ld_b, void* stream);
+                       float* flow_a, int ld_a, float* flow_b, int ld_b, int fmt_b, void* stream);
+/* fmt_b VFML_FMT_S16: flow_b points at channel 4 of a split-row unit (16-byte aligned + 8): the four
+ * flow values become the second quad of that unit (hi at +0..7, lo at +16..23 of the quad slot). */
 /* coords1[p] = (x, y, x, y) */
 int vfml_coords_init(float* coords1, int n, int h, int w, void* stream);
 

@@ -122,6 +122,116 @@ def test_conv2d_as_gemm_correlation(gpu, precision):
     assert (got[:, S:] == 0).all()
 
 
+def s16_decode(flat, rows, ld, c):
+    """split rows (FMT_S16) device buffer -> f32 [rows, c] on the host."""
+    u = flat.view(torch.float16).view(rows, ld // 8, 2, 8).float().cpu()
+    return (u[:, :, 0] + u[:, :, 1]).reshape(rows, ld)[:, :c]
+
+
+def test_to_s16_roundtrip(gpu):
+    from vfml import hip
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(50, 20, generator=g) * 3
+    dst = torch.zeros(50 * 24, device=gpu)
+    hip.to_s16(x.cuda().reshape(-1), 50, 20, 20, dst, 24)
+    rec = s16_decode(dst, 50, 24, 24)
+    assert (rec[:, 20:] == 0).all()
+    assert ((rec[:, :20] - x).abs() <= 2.0 ** -21 * x.abs() + 2.0 ** -24).all()
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw", [(64, 128, 3, 3), (256, 124, 3, 3), (128, 64, 1, 1), (512, 256, 1, 5)])
+def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw):
+    """Split-row (S16) activations in, split-row activations out == the f32-in/f32-out result."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(13)
+    n, H, W = 2, 13, 21
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=(kh // 2, kw // 2))).float()
+    w = as_weight(pack_conv_weight(wt), cout, "f16x3")
+    x16 = torch.empty(n * H * W * cin, device=gpu)
+    hip.to_s16(nhwc(x), n * H * W, cin, cin, x16, cin)
+    ldo = (cout + 7) // 8 * 8 + 8
+    out = torch.zeros(n * H * W * ldo, device=gpu)
+    hip.conv2d(x16, cin, cin, n, H, W, w, b.cuda(), cout, kh, kw, out, ldo, pad_h=kh // 2, pad_w=kw // 2,
+               epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16)
+    got = s16_decode(out, n * H * W, ldo, ldo)
+    assert (got[:, (cout + 3) // 4 * 4:] == 0).all()            # nothing written past cout
+    got = got[:, :cout].view(n, H, W, cout).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < CONV_TOL["f16x3"]
+
+
+def test_gru_epilogues_in_split_rows(gpu):
+    """The engine's state buffer in split rows: gates read h / z as S16 aux operands, write S16."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(14)
+    n, H, W = 1, 10, 16
+    h = torch.tanh(torch.randn(n, 128, H, W, generator=g))
+    x = torch.randn(n, 384, H, W, generator=g)
+    wz, wr, wq = [torch.randn(128, 512, 5, 1, generator=g) / math.sqrt(512 * 5) for _ in range(3)]
+    bz, br, bq = [torch.randn(128, generator=g) * 0.1 for _ in range(3)]
+    hx = torch.cat([h, x], 1)
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=(2, 0)))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=(2, 0)))
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq, bq, padding=(2, 0)))
+    href = (1 - z) * h + z * q
+    LD, Z, RH, HH, X = 768, 0, 128, 256, 384
+    P = n * H * W
+    G = torch.zeros(P * LD, device=gpu)
+    hip.to_s16(nhwc(hx), P, 512, 512, G, LD, dst_off=HH)
+    S = hip.FMT_S16
+    wzr = as_weight(torch.cat([pack_conv_weight(wz), pack_conv_weight(wr)]), 256, "f16x3")
+    hip.conv2d(G, 512, LD, n, H, W, wzr, torch.cat([bz, br]).cuda(), 256, 5, 1, G, LD, in0_off=HH, out_off=Z, pad_h=2,
+               epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=LD, aux0_off=HH, in_fmt=S, out_fmt=S, aux_fmt=S)
+    hip.conv2d(G, 128, LD, n, H, W, as_weight(pack_conv_weight(wq), 128, "f16x3"), bq.cuda(), 128, 5, 1, G, LD,
+               in0_off=RH, out_off=HH, in1=G, c1=384, ld1=LD, in1_off=X, pad_h=2, epilogue=hip.EPI_GRU_Q,
+               aux0=G, ld_aux0=LD, aux0_off=Z, aux1=G, ld_aux1=LD, aux1_off=HH, in_fmt=S, out_fmt=S, aux_fmt=S)
+    got = s16_decode(G, P, LD, LD).view(n, H, W, LD).permute(0, 3, 1, 2)
+    assert rel_err(got[:, Z:Z + 128], z) < 3e-6
+    assert rel_err(got[:, RH:RH + 128], r * h) < 3e-6
+    assert rel_err(got[:, HH:HH + 128], href) < 5e-6
+    assert rel_err(got[:, X:], x) < 1e-6
+
+
+def test_lookup_and_flow_in_split_rows(gpu):
+    from oracle import mof_oracle as mo
+    from vfml import hip
+    h, w, radius, levels = 16, 20, 4, 4
+    pyr = _pyramid_inputs(21, h, w, levels)
+    coords = mo.coords_grid(1, h, w) + torch.randn(1, 2, h, w, generator=torch.Generator().manual_seed(22)) * 3
+    blk = mo.CorrBlock.__new__(mo.CorrBlock)
+    blk.num_levels, blk.radius, blk.pyramid = levels, radius, pyr
+    ref = blk(coords)[0].permute(1, 2, 0).reshape(h * w, -1)
+    P = h * w
+    hl = [p.shape[-2] for p in pyr]
+    wl = [p.shape[-1] for p in pyr]
+    ld = [a * b for a, b in zip(hl, wl)]
+    dev = [p.reshape(P, -1).cuda().reshape(-1) for p in pyr]
+    c4 = torch.zeros(P, 4)
+    c4[:, :2] = coords[0].permute(1, 2, 0).reshape(P, 2)
+    out = torch.full((P * 664,), 7.0, device=gpu)          # [.. 328 | 328 | 8 spare]
+    hip.corr_lookup(dev, hl, wl, ld, radius, P, c4.cuda().reshape(-1), 0, 4, out, 328, 664, out_fmt=hip.FMT_S16)
+    got = s16_decode(out, P, 664, 664)
+    assert (got[:, 328:652] - ref).abs().max().item() < 2e-5
+    assert (got[:, 652:656] == 0).all()                     # zero-filled up to the whole unit
+    # flow into the second quad of a unit, first quad untouched
+    coords1 = torch.empty(P * 4, device=gpu)
+    hip.coords_init(coords1, 1, h, w)
+    delta = torch.randn(P, 4, generator=torch.Generator().manual_seed(23))
+    buf = torch.zeros(P * 16, device=gpu)
+    hip.to_s16(torch.ones(P * 4, device=gpu), P, 4, 4, buf, 16, dst_off=8)
+    hip.coords_update(coords1, delta.cuda().reshape(-1), 1, h, w, flow_b=buf, ld_b=16, flow_b_off=12,
+                      fmt_b=hip.FMT_S16)
+    dec = s16_decode(buf, P, 16, 16)
+    assert (dec[:, 8:12] == 1).all() and (dec[:, :8] == 0).all()
+    grid = mo.coords_grid(1, h, w)[0].permute(1, 2, 0).reshape(P, 2)
+    want = (torch.cat([grid, grid], 1) + delta) - torch.cat([grid, grid], 1)
+    assert ((dec[:, 12:16] - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -24).all()
+
+
 def test_conv2d_rejects_bad_arguments(gpu):
     from vfml import hip
     x = torch.zeros(64, device=gpu)

@@ -5,15 +5,22 @@ sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, 
 import torch
 from vfml import hip
 
-def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20):
+def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=False):
     ld = ld or cin
     x = torch.randn(n * h * w * ld, device="cuda")
+    fmt = hip.FMT_S16 if s16 else hip.FMT_F32
+    if s16:
+        x16 = torch.empty_like(x)
+        hip.to_s16(x, n * h * w, ld, ld, x16, ld)
+        x = x16
+        name += " [S16]"
     wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
     b = torch.randn(cout, device="cuda")
     wobj = wt if prec == "f32" else hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
     out = torch.empty(n * h * w * cout, device="cuda")
     def run():
-        hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU)
+        hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
+                   in_fmt=fmt, out_fmt=fmt)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,6 +30,17 @@ def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20):
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * n * h * w * kh * kw * cin * cout
     print(f"{name:46s} M={n*h*w:8d} K={kh*kw*cin:5d} cout={cout:5d}  {ms*1000:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s16":
+    bench("gru 1x5 c512->256", 3, 135, 240, 512, 256, 1, 5, s16=True)
+    bench("gru 1x5 c512->256 ld768", 3, 135, 240, 512, 256, 1, 5, ld=768, s16=True)
+    bench("1x5 c512->128", 3, 135, 240, 512, 128, 1, 5, s16=True)
+    bench("3x3 c256->256", 3, 135, 240, 256, 256, 3, 3, s16=True)
+    bench("3x3 c256->192", 3, 135, 240, 256, 192, 3, 3, s16=True)
+    bench("1x1 c656->256", 3, 135, 240, 656, 256, 1, 1, s16=True)
+    bench("gemm 32400x32400x256", 1, 1, 32400, 256, 32400, 1, 1, reps=5, s16=True)
+    bench("gemm 32400x8040x256", 1, 1, 32400, 256, 8040, 1, 1, reps=5, s16=True)
+    sys.exit(0)
 
 if __name__ == "__main__":
     bench("gru 1x5 c512->256 (3x135x240)", 3, 135, 240, 512, 256, 1, 5)

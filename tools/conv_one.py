@@ -10,6 +10,12 @@ wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
 b = torch.randn(cout, device="cuda")
 wobj = hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
 out = torch.empty(n * h * w * cout, device="cuda")
+fmt = hip.FMT_S16 if os.environ.get("S16", "1") == "1" else hip.FMT_F32
+if fmt == hip.FMT_S16:
+    x16 = torch.empty_like(x)
+    hip.to_s16(x, n * h * w, cin, cin, x16, cin)
+    x = x16
 for _ in range(5):
-    hip.conv2d(x, cin, cin, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU)
+    hip.conv2d(x, cin, cin, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
+               in_fmt=fmt, out_fmt=fmt)
 torch.cuda.synchronize()

@@ -26,6 +26,7 @@
 // Epilogue: the accumulator tile is transposed through LDS and written as float4 rows (bias,
 // activation and the GRU gate math applied on the way).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #include "vfml_common.h"
 
 namespace {
@@ -63,6 +64,7 @@ struct SplitArgs {
   float out_scale, w_inv;
   int mtiles, ntiles;
   int vec_ok;  // out/aux/bias 16-byte aligned and ldo, ld_aux % 4 == 0 -> float4 epilogue
+  int out16, aux16;   // output / aux operands in the split-row format (VFML_FMT_S16)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -102,12 +104,17 @@ __device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float
 // BIGC: every source row has >= BK channels, so a K step never spans more than two taps and the
 // (channel, tap) state advances without divisions.  !BIGC (4-channel stem / flow convs) recomputes
 // it by division each step.
-template <int BN, int WM, int WN, bool BIGC>
-__global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs a) {
+// IN16: the sources are already in the split-row format (VFML_FMT_S16: per pixel and 8-channel group
+// 16 B of hi halves then 16 B of lo halves), so the two 16-byte loads of a unit ARE its hi and lo
+// LDS images and no conversion happens in the loop.
+template <int BN, int WM, int WN, bool BIGC, bool IN16>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void conv_gemm_split_kernel(const SplitArgs a) {
+  constexpr int NT = WM * WN * 64;  // threads: 256 (4 waves) or 512 (8 waves, finer MFMA interleave per SIMD)
+  constexpr int LR = NT / 4;        // rows covered by one pass of the loader (4 k-groups per row)
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
-  constexpr int AU = BM / 64;   // A units per thread per K step (each unit: 8 k of one row)
-  constexpr int BU = BN / 64;   // B units per thread per K step; BN=32 -> threads >= 128 idle on B
+  constexpr int AU = BM / LR;   // A units per thread per K step (each unit: 8 k of one row)
+  constexpr int BU = BN / LR;   // B units per thread per K step; 0 -> only threads with lrow < BN load B
   constexpr int BUN = BU > 0 ? BU : 1;
   constexpr int RSA = BM + 2;   // unit row stride per k-group (padded)
   constexpr int RSB = BN + 2;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
 
   const int t = threadIdx.x;
   const int kg = t & 3;
-  const int lrow = t >> 2;  // 0..63
+  const int lrow = t >> 2;  // 0..LR-1
 
   // Per-row gather state, fixed for the whole K loop.  All A offsets are 32-bit element offsets
   // (the host checks that every source spans < 2^31 floats).
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
   unsigned long long tapok[AU];
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
-    const int m = m0 + lrow + 64 * i;
+    const int m = m0 + lrow + LR * i;
     int iy0[1], ix0[1];   // (kept as arrays of one to reuse the expressions below)
     tapok[i] = 0ull;
     if (m < a.M) {
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
   int colbase[BUN];
 #pragma unroll
   for (int i = 0; i < BUN; ++i) {
-    const int col = n0 + lrow + 64 * i;
+    const int col = n0 + lrow + LR * i;
     const bool colok = (BU > 0 || lrow < BN) && col < a.cout;
     colbase[i] = colok ? col * a.Kp * 2 : 0x40000000;
   }
@@ -197,10 +204,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.whi), 0, a.bytesw, 0x00020000);
   const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wlo), 0, a.bytesw, 0x00020000);
 
+  int offs16[AU];
   // Issues the loads of the K step starting at k0 (must be called in increasing k0 order).
   auto load_tile = [&](Stage& s, int k0) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      if (IN16 && hf == 1) {   // second 16 bytes of the same unit: the lo halves
+#pragma unroll
+        for (int i = 0; i < AU; ++i) s.a[i][1] = __builtin_bit_cast(f32x4, bload16(r0, offs16[i]));
+        break;
+      }
       const bool kok = k0 + kg * 8 + hf * 4 < a.K;
       int c = kc[hf];
       const int ky = kky[hf], kx = kkx[hf];
@@ -214,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
         const bool ok = (tapok[i] >> tap) & 1ull;
         const int off = ((s1 ? rp1[i] : rp0[i]) + tapoff) * 4;
         s.a[i][hf] = __builtin_bit_cast(f32x4, bload16(r0, ok ? off : OOB));
+        if (IN16) offs16[i] = ok ? off + 16 : OOB;
       }
       if (BIGC) {
         int cn = kc[hf] + BK;
@@ -247,16 +261,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
       U8 hi, lo;
-      split4(s.a[i][0], hi, lo, 0);
-      split4(s.a[i][1], hi, lo, 4);
-      sAh[buf * SA + kg * RSA + lrow + 64 * i] = hi.v;
-      sAl[buf * SA + kg * RSA + lrow + 64 * i] = lo.v;
+      if (IN16) {
+        hi.v = __builtin_bit_cast(h16x8, s.a[i][0]);
+        lo.v = __builtin_bit_cast(h16x8, s.a[i][1]);
+      } else {
+        split4(s.a[i][0], hi, lo, 0);
+        split4(s.a[i][1], hi, lo, 4);
+      }
+      sAh[buf * SA + kg * RSA + lrow + LR * i] = hi.v;
+      sAl[buf * SA + kg * RSA + lrow + LR * i] = lo.v;
     }
 #pragma unroll
     for (int i = 0; i < BUN; ++i) {
       if (BU > 0 || lrow < BN) {
-        sBh[buf * SB + kg * RSB + lrow + 64 * i] = s.bh[i];
-        sBl[buf * SB + kg * RSB + lrow + 64 * i] = s.bl[i];
+        sBh[buf * SB + kg * RSB + lrow + LR * i] = s.bh[i];
+        sBl[buf * SB + kg * RSB + lrow + LR * i] = s.bl[i];
       }
     }
   };
@@ -343,61 +362,95 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(const SplitArgs
       }
   __syncthreads();
 
-  constexpr int C4 = BN / 4;         // float4 columns per tile row
-  constexpr int RPP = 256 / C4;      // rows per pass
-  const int c4 = t % C4;
-  const int gcol = n0 + c4 * 4;
+  // 8 channels (one split-row unit) per thread, as two quads
+  constexpr int C8 = BN / 8;
+  constexpr int RPP = NT / C8;       // rows per pass
+  const int c8 = t % C8;
+  const int gcol = n0 + c8 * 8;
   if (gcol >= a.cout) return;
-  const bool full4 = a.vec_ok && gcol + 4 <= a.cout;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  const int epi = a.epilogue;
+  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (a.bias) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (gcol + e < a.cout) bias4[e] = a.bias[gcol + e];
+    for (int e = 0; e < 8; ++e)
+      if (gcol + e < a.cout) bias4[e >> 2][e & 3] = a.bias[gcol + e];
   }
-  const int epi = a.epilogue;
-  const bool lowhalf = gcol < a.split;   // split is a multiple of 4: a float4 never straddles it
-  for (int row = t / C4; row < BM; row += RPP) {
+  // reads 4 channels at (row, col) of an aux operand in either format
+  auto aux4 = [&](const float* base, int ld, int64_t row, int col) -> f32x4 {
+    f32x4 x;
+    if (a.aux16) {
+      const char* u = reinterpret_cast<const char*>(base + row * ld + (col & ~7)) + (col & 4) * 2;
+      const h16x2 h0 = *reinterpret_cast<const h16x2*>(u), h1 = *reinterpret_cast<const h16x2*>(u + 4);
+      const h16x2 l0 = *reinterpret_cast<const h16x2*>(u + 16), l1 = *reinterpret_cast<const h16x2*>(u + 20);
+      x[0] = (float)h0[0] + (float)l0[0];
+      x[1] = (float)h0[1] + (float)l0[1];
+      x[2] = (float)h1[0] + (float)l1[0];
+      x[3] = (float)h1[1] + (float)l1[1];
+    } else if (a.vec_ok) {
+      x = *reinterpret_cast<const f32x4*>(base + row * ld + col);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = base[row * ld + col + e];
+    }
+    return x;
+  };
+  for (int row = t / C8; row < BM; row += RPP) {
     const int grow = m0 + row;
     if (grow >= a.M) break;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c4 * 4]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + bias4[e]) * a.out_scale;
-    float* o = a.out + (int64_t)grow * a.ldo + gcol;
-    if (full4) {
+    for (int q = 0; q < 2; ++q) {
+      const int col = gcol + 4 * q;
+      if (col >= a.cout) break;
+      const bool lowhalf = col < a.split;   // split is a multiple of 4: a quad never straddles it
+      const int nvalid = a.cout - col >= 4 ? 4 : a.cout - col;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + bias4[q][e]) * a.out_scale;
       f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-      if (epi == VFML_EPI_GRU_ZR && !lowhalf)
-        x0 = *reinterpret_cast<const f32x4*>(a.aux0 + (int64_t)grow * a.ld_aux0 + (gcol - a.split));
-      if (epi == VFML_EPI_GRU_Q) {
-        x0 = *reinterpret_cast<const f32x4*>(a.aux0 + (int64_t)grow * a.ld_aux0 + gcol);
-        x1 = *reinterpret_cast<const f32x4*>(a.aux1 + (int64_t)grow * a.ld_aux1 + gcol);
+      if (nvalid == 4) {
+        if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0 = aux4(a.aux0, a.ld_aux0, grow, col - a.split);
+        if (epi == VFML_EPI_GRU_Q) {
+          x0 = aux4(a.aux0, a.ld_aux0, grow, col);
+          x1 = aux4(a.aux1, a.ld_aux1, grow, col);
+        }
+      } else {
+        for (int e = 0; e < nvalid; ++e) {   // ragged tail: f32 operands only (host check)
+          if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e - a.split];
+          if (epi == VFML_EPI_GRU_Q) {
+            x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
+            x1[e] = a.aux1[(int64_t)grow * a.ld_aux1 + col + e];
+          }
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = epi1(v[e], epi, lowhalf, x0[e], x1[e]);
-      *reinterpret_cast<f32x4*>(o) = v;
-    } else {
-      for (int e = 0; e < 4 && gcol + e < a.cout; ++e) {
-        float x0 = 0.f, x1 = 0.f;
-        const bool lh = gcol + e < a.split;
-        if (epi == VFML_EPI_GRU_ZR && !lh) x0 = a.aux0[(int64_t)grow * a.ld_aux0 + (gcol + e - a.split)];
-        if (epi == VFML_EPI_GRU_Q) {
-          x0 = a.aux0[(int64_t)grow * a.ld_aux0 + gcol + e];
-          x1 = a.aux1[(int64_t)grow * a.ld_aux1 + gcol + e];
+      if (a.out16) {
+        // hi quad at unit + 8q bytes, lo quad at unit + 16 + 8q (cout % 4 == 0, host check)
+        U8 hi, lo;
+        split4(v, hi, lo, 0);
+        char* u = reinterpret_cast<char*>(a.out + (int64_t)grow * a.ldo + gcol) + 8 * q;
+        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+        *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+      } else {
+        float* o = a.out + (int64_t)grow * a.ldo + col;
+        if (nvalid == 4 && a.vec_ok) {
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+          for (int e = 0; e < nvalid; ++e) o[e] = v[e];
         }
-        o[e] = epi1(v[e], epi, lh, x0, x1);
       }
     }
   }
 }
 
-template <int BN, int WM, int WN, bool BIGC>
+template <int BN, int WM, int WN, bool BIGC, bool IN16>
 int launch(const SplitArgs& a, hipStream_t s) {
   constexpr size_t stage = 2 * 2 * (KG * (BM + 2) + KG * (BN + 2)) * 16;
   constexpr size_t ctile = (size_t)BM * (BN + 4) * 4;
   constexpr size_t lds = stage > ctile ? stage : ctile;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<BN, WM, WN, BIGC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<BN, WM, WN, BIGC, IN16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -405,7 +458,7 @@ int launch(const SplitArgs& a, hipStream_t s) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_split_kernel<BN, WM, WN, BIGC>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_split_kernel<BN, WM, WN, BIGC, IN16>), dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
@@ -425,7 +478,36 @@ __global__ void split_f16_kernel(const float* __restrict__ src, int64_t rows, in
   }
 }
 
+// f32 rows -> split rows, one quad (4 channels) per thread
+__global__ void to_s16_kernel(const float* __restrict__ src, int64_t rows, int c, int lds, float* __restrict__ dst,
+                              int ldd) {
+  const int q4 = c / 4;
+  const int64_t total = rows * q4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / q4;
+    const int col = (int)(i - row * q4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * lds + col);
+    U8 hi, lo;
+    split4(v, hi, lo, 0);
+    char* u = reinterpret_cast<char*>(dst + row * ldd + (col & ~7)) + (col & 4) * 2;
+    *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+    *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+  }
+}
+
 }  // namespace
+
+extern "C" int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream) {
+  VFML_REQUIRE(src && dst && rows > 0 && c > 0 && c % 4 == 0 && ld_src >= c && ld_src % 4 == 0 && ld_dst % 8 == 0 &&
+               ld_dst >= ((c + 7) & ~7), "vfml_to_s16: bad shape (c %% 4, ld_src %% 4, ld_dst %% 8)");
+  VFML_REQUIRE(vfml_aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0, "vfml_to_s16: alignment");
+  const int64_t total = rows * (c / 4);
+  int64_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(to_s16_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, rows, c,
+                     ld_src, dst, ld_dst);
+  return vfml_check_launch("vfml_to_s16");
+}
 
 extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, float scale, void* hi, void* lo, int kp,
                               void* stream) {
@@ -442,8 +524,22 @@ extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, flo
 }
 
 extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
-                                 void* stream) {
+                                 int in_fmt, int out_fmt, int aux_fmt, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
+  VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
+               (aux_fmt == VFML_FMT_F32 || aux_fmt == VFML_FMT_S16), "vfml_conv2d_split: bad format selector");
+  const bool in16 = in_fmt == VFML_FMT_S16;
+  if (in16)
+    VFML_REQUIRE(d->c0 % 8 == 0 && d->ld0 % 8 == 0 && d->c1 % 8 == 0 && d->ld1 % 8 == 0 && d->c0 + d->c1 >= 32,
+                 "vfml_conv2d_split: split-row sources need channel counts / strides that are multiples of 8 and >= 32 channels");
+  if (out_fmt == VFML_FMT_S16)
+    VFML_REQUIRE(d->cout % 4 == 0 && d->ldo % 8 == 0 && vfml_aligned16(d->out) && (reinterpret_cast<uintptr_t>(d->out) & 31u) == 0,
+                 "vfml_conv2d_split: split-row output needs cout %% 4 == 0, ldo %% 8 == 0 and a 32-byte aligned out");
+  if (aux_fmt == VFML_FMT_S16)
+    VFML_REQUIRE(d->cout % 4 == 0 && (!d->aux0 || (d->ld_aux0 % 8 == 0 && (reinterpret_cast<uintptr_t>(d->aux0) & 31u) == 0)) &&
+                 (!d->aux1 || (d->ld_aux1 % 8 == 0 && (reinterpret_cast<uintptr_t>(d->aux1) & 31u) == 0)) &&
+                 (d->epilogue != VFML_EPI_GRU_ZR || d->split % 8 == 0),
+                 "vfml_conv2d_split: split-row aux operands need 32-byte aligned bases, ld %% 8 == 0, cout %% 4 == 0");
   VFML_REQUIRE(d->in0 && w_hi && w_lo && d->out, "vfml_conv2d_split: null in0/w_hi/w_lo/out");
   VFML_REQUIRE(d->c0 > 0 && d->c0 % 4 == 0 && d->ld0 % 4 == 0 && d->ld0 >= d->c0,
                "vfml_conv2d_split: c0=%d ld0=%d must be multiples of 4 with ld0>=c0", d->c0, d->ld0);
@@ -501,15 +597,31 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   a.vec_ok = vfml_aligned16(d->out) && d->ldo % 4 == 0 &&
              (!d->aux0 || (vfml_aligned16(d->aux0) && d->ld_aux0 % 4 == 0)) &&
              (!d->aux1 || (vfml_aligned16(d->aux1) && d->ld_aux1 % 4 == 0));
+  a.out16 = out_fmt == VFML_FMT_S16;
+  a.aux16 = aux_fmt == VFML_FMT_S16;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool bigc = a.ctot >= BK;
+  if (in16) {   // split-row sources: every slice is a multiple of 8 channels and >= one K step wide
+    if (d->cout > 64) {
+      a.ntiles = (d->cout + 127) / 128;
+      static const int waves8 = getenv("VFML_WAVES8") ? atoi(getenv("VFML_WAVES8")) : 0;
+      if (waves8 == 1) return launch<128, 4, 2, true, true>(a, s);
+      if (waves8 == 2) return launch<128, 2, 4, true, true>(a, s);
+      return launch<128, 2, 2, true, true>(a, s);
+    } else if (d->cout > 32) {
+      a.ntiles = 1;
+      return launch<64, 2, 2, true, true>(a, s);
+    }
+    a.ntiles = 1;
+    return launch<32, 4, 1, true, true>(a, s);
+  }
   if (d->cout > 64) {
     a.ntiles = (d->cout + 127) / 128;
-    return bigc ? launch<128, 2, 2, true>(a, s) : launch<128, 2, 2, false>(a, s);
+    return bigc ? launch<128, 2, 2, true, false>(a, s) : launch<128, 2, 2, false, false>(a, s);
   } else if (d->cout > 32) {
     a.ntiles = 1;
-    return bigc ? launch<64, 2, 2, true>(a, s) : launch<64, 2, 2, false>(a, s);
+    return bigc ? launch<64, 2, 2, true, false>(a, s) : launch<64, 2, 2, false, false>(a, s);
   }
   a.ntiles = 1;
-  return bigc ? launch<32, 4, 1, true>(a, s) : launch<32, 4, 1, false>(a, s);
+  return bigc ? launch<32, 4, 1, true, false>(a, s) : launch<32, 4, 1, false, false>(a, s);
 }

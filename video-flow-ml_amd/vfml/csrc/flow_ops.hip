@@ -16,6 +16,7 @@ struct LookupArgs {
   int levels, radius, nq;
   const float* coords; int ld_coords;
   float* out; int ld_out;
+  int out16;
 };
 
 // One wave per query.  Per level the window's (2r+1)^2 bilinear samples all share the same
@@ -61,7 +62,14 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
   if (!live) return;
   const int nout = a.levels * win * win;
   float* o = a.out + (int64_t)q * a.ld_out;
-  for (int c = lane; c < nout; c += 64) {
+  const int nwrite = a.out16 ? (nout + 7) & ~7 : nout;   // split rows: zero-fill up to a whole unit
+  for (int c = lane; c < nwrite; c += 64) {
+    if (c >= nout) {
+      _Float16* u = reinterpret_cast<_Float16*>(o + (c & ~7));
+      u[c & 7] = (_Float16)0.f;
+      u[8 + (c & 7)] = (_Float16)0.f;
+      continue;
+    }
     const int l = c / (win * win);
     const int rem = c - l * win * win;
     const int i = rem / win, j = rem - i * win;  // i: x offset index, j: y offset index
@@ -69,7 +77,17 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
     const float* p = &patch[wv][l][j * side + i];
     // grid_sample's bilinear: nw*(1-fx)(1-fy) + ne*fx(1-fy) + sw*(1-fx)fy + se*fx*fy
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
-    o[c] = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[side] * (wx0 * fy) + p[side + 1] * (fx * fy);
+    const float v = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[side] * (wx0 * fy) + p[side + 1] * (fx * fy);
+    if (a.out16) {
+      typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
+      const fp16x2_ hh = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+      const fp16x2_ ll = __builtin_amdgcn_cvt_pkrtz(v - (float)hh[0], 0.f);
+      __fp16* u = reinterpret_cast<__fp16*>(o + (c & ~7));
+      u[c & 7] = hh[0];
+      u[8 + (c & 7)] = ll[0];
+    } else {
+      o[c] = v;
+    }
   }
 }
 
@@ -83,7 +101,8 @@ __global__ void coords_init_kernel(f32x4* __restrict__ coords, int h, int w, int
 }
 
 __global__ void coords_update_kernel(f32x4* __restrict__ coords, const f32x4* __restrict__ delta, int h, int w,
-                                     int64_t total, float* __restrict__ fa, int lda, float* __restrict__ fb, int ldb) {
+                                     int64_t total, float* __restrict__ fa, int lda, float* __restrict__ fb, int ldb,
+                                     int b16) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
     f32x4 c = coords[p];
     if (delta) {
@@ -94,7 +113,23 @@ __global__ void coords_update_kernel(f32x4* __restrict__ coords, const f32x4* __
     const float y = (float)(int)((p / w) % h);
     const f32x4 f = {c[0] - x, c[1] - y, c[2] - x, c[3] - y};
     if (fa) *reinterpret_cast<f32x4*>(fa + p * lda) = f;
-    if (fb) *reinterpret_cast<f32x4*>(fb + p * ldb) = f;
+    if (fb) {
+      if (b16) {   // second quad of a split-row unit: hi halves at +0 (8 B), lo halves 16 B further
+        typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
+        const fp16x2_ h0 = __builtin_amdgcn_cvt_pkrtz(f[0], f[1]), h1 = __builtin_amdgcn_cvt_pkrtz(f[2], f[3]);
+        const fp16x2_ l0 = __builtin_amdgcn_cvt_pkrtz(f[0] - (float)h0[0], f[1] - (float)h0[1]);
+        const fp16x2_ l1 = __builtin_amdgcn_cvt_pkrtz(f[2] - (float)h1[0], f[3] - (float)h1[1]);
+        // fb points at channel 4 of the unit = byte 16 of it in f32 addressing; the quad slot of the
+        // hi halves is byte 8 of the unit
+        char* u = reinterpret_cast<char*>(fb + p * ldb) - 16;
+        *reinterpret_cast<fp16x2_*>(u + 8) = h0;
+        *reinterpret_cast<fp16x2_*>(u + 12) = h1;
+        *reinterpret_cast<fp16x2_*>(u + 24) = l0;
+        *reinterpret_cast<fp16x2_*>(u + 28) = l1;
+      } else {
+        *reinterpret_cast<f32x4*>(fb + p * ldb) = f;
+      }
+    }
   }
 }
 
@@ -151,14 +186,19 @@ inline int grid_for(int64_t items, int block) {
 
 extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                 int levels, int radius, int nq, const float* coords, int ld_coords, float* out,
-                                int ld_out, void* stream) {
+                                int ld_out, int out_fmt, void* stream) {
+  VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
   VFML_REQUIRE(pyr && hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
   VFML_REQUIRE(levels >= 1 && levels <= MAX_LEVELS, "vfml_corr_lookup: levels=%d out of [1,%d]", levels, MAX_LEVELS);
   VFML_REQUIRE(radius >= 1 && radius <= MAX_RADIUS, "vfml_corr_lookup: radius=%d out of [1,%d]", radius, MAX_RADIUS);
   VFML_REQUIRE(nq > 0 && ld_coords >= 2, "vfml_corr_lookup: bad nq/ld_coords");
   const int nout = levels * (2 * radius + 1) * (2 * radius + 1);
   VFML_REQUIRE(ld_out >= nout, "vfml_corr_lookup: ld_out=%d < %d channels", ld_out, nout);
+  if (out_fmt == VFML_FMT_S16)
+    VFML_REQUIRE(ld_out % 8 == 0 && ld_out >= ((nout + 7) & ~7) && (reinterpret_cast<uintptr_t>(out) & 31u) == 0,
+                 "vfml_corr_lookup: split-row output needs a 32-byte aligned out and ld_out %% 8 == 0");
   LookupArgs a;
+  a.out16 = out_fmt == VFML_FMT_S16;
   for (int l = 0; l < levels; ++l) {
     VFML_REQUIRE(pyr[l] && hl[l] > 0 && wl[l] > 0 && ld[l] >= hl[l] * wl[l], "vfml_corr_lookup: bad level %d", l);
     a.pyr[l] = pyr[l]; a.hl[l] = hl[l]; a.wl[l] = wl[l]; a.ld[l] = ld[l];
@@ -181,7 +221,11 @@ extern "C" int vfml_coords_init(float* coords1, int n, int h, int w, void* strea
 }
 
 extern "C" int vfml_coords_update(float* coords1, const float* delta, int n, int h, int w, float* flow_a, int ld_a,
-                                  float* flow_b, int ld_b, void* stream) {
+                                  float* flow_b, int ld_b, int fmt_b, void* stream) {
+  VFML_REQUIRE(fmt_b == VFML_FMT_F32 || fmt_b == VFML_FMT_S16, "vfml_coords_update: bad fmt_b");
+  if (fmt_b == VFML_FMT_S16 && flow_b)
+    VFML_REQUIRE((reinterpret_cast<uintptr_t>(flow_b) & 31u) == 16 && ld_b % 8 == 0,
+                 "vfml_coords_update: split-row flow_b must point at channel 4 of a unit (ld_b %% 8 == 0)");
   VFML_REQUIRE(coords1 && n > 0 && h > 0 && w > 0, "vfml_coords_update: bad argument");
   VFML_REQUIRE(vfml_aligned16(coords1) && vfml_aligned16(delta) && vfml_aligned16(flow_a) && vfml_aligned16(flow_b),
                "vfml_coords_update: alignment");
@@ -190,7 +234,7 @@ extern "C" int vfml_coords_update(float* coords1, const float* delta, int n, int
   const int64_t total = (int64_t)n * h * w;
   hipLaunchKernelGGL(coords_update_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), (f32x4*)coords1, (const f32x4*)delta, h, w, total, flow_a,
-                     ld_a, flow_b, ld_b);
+                     ld_a, flow_b, ld_b, fmt_b == VFML_FMT_S16 ? 1 : 0);
   return vfml_check_launch("vfml_coords_update");
 }
 

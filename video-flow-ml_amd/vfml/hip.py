@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip"]
 
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q = range(7)
+FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 
 
 class ConvDesc(ctypes.Structure):
@@ -66,7 +67,8 @@ def lib():
     L.vfml_last_error.restype = c_char_p
     L.vfml_abi_version.restype = c_int
     L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
-    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_void_p]
+    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
+    L.vfml_to_s16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_frames_to_nhwc4.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
     L.vfml_instnorm_workspace_bytes.restype = c_int64
@@ -75,21 +77,21 @@ def lib():
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                   c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]
+                                   c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
-                                     c_void_p]
+                                     c_int, c_void_p]
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 1:
+    if L.vfml_abi_version() != 2:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
 
 
 EXPORTS = [
-    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
+    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
     "vfml_convex_upsample", "vfml_last_error", "vfml_abi_version",
 ]
@@ -178,7 +180,8 @@ class SplitWeight:
 
 def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, stride=1, pad_h=0, pad_w=0,
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
-           aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0):
+           aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
+           in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers)."""
     d = ConvDesc()
@@ -198,8 +201,11 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         def launch():
             _check(lib().vfml_conv2d_split(ctypes.byref(d), c_void_p(weight.hi.data_ptr() + 2 * weight_off * weight.kp),
                                            c_void_p(weight.lo.data_ptr() + 2 * weight_off * weight.kp), weight.kp,
-                                           weight.scale, _stream()), "vfml_conv2d_split")
+                                           weight.scale, in_fmt, out_fmt, aux_fmt, _stream()), "vfml_conv2d_split")
     else:
+        if in_fmt != FMT_F32 or out_fmt != FMT_F32 or aux_fmt != FMT_F32:
+            raise ValueError("the exact-f32 kernel (vfml_conv2d) takes and writes plain f32 activations only")
+
         def launch():
             _check(lib().vfml_conv2d(ctypes.byref(d), _stream()), "vfml_conv2d")
     if _PROFILE is None:
@@ -246,22 +252,30 @@ def avgpool2x2(x, n, h, w, c, out):
     _check(lib().vfml_avgpool2x2(_ptr(_dev(x)), n, h, w, c, _ptr(_dev(out)), _stream()), "vfml_avgpool2x2")
 
 
-def corr_lookup(pyr, hl, wl, ld, radius, nq, coords, coords_off, ld_coords, out, out_off, ld_out, row_off=0):
+def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):
+    """f32 rows [rows][c] -> split rows (FMT_S16) at float offset dst_off of dst."""
+    _check(lib().vfml_to_s16(_ptr(_dev(src), src_off), rows, c, ld_src, _ptr(_dev(dst), dst_off), ld_dst, _stream()),
+           "vfml_to_s16")
+
+
+def corr_lookup(pyr, hl, wl, ld, radius, nq, coords, coords_off, ld_coords, out, out_off, ld_out, row_off=0,
+                out_fmt=FMT_F32):
     """pyr: list of flat float32 device tensors (one per level); row_off: first query row inside each level."""
     L = len(pyr)
     ptrs = (c_void_p * L)(*[p.data_ptr() + 4 * row_off * ld[i] for i, p in enumerate(pyr)])
     _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius, nq,
                                   _ptr(_dev(coords), coords_off), ld_coords, _ptr(_dev(out), out_off), ld_out,
-                                  _stream()), "vfml_corr_lookup")
+                                  out_fmt, _stream()), "vfml_corr_lookup")
 
 
 def coords_init(coords1, n, h, w):
     _check(lib().vfml_coords_init(_ptr(_dev(coords1)), n, h, w, _stream()), "vfml_coords_init")
 
 
-def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None, ld_b=0, flow_b_off=0):
+def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None, ld_b=0, flow_b_off=0,
+                  fmt_b=FMT_F32):
     _check(lib().vfml_coords_update(_ptr(_dev(coords1)), _ptr(delta), n, h, w,
-                                    _ptr(flow_a, flow_a_off), ld_a, _ptr(flow_b, flow_b_off), ld_b, _stream()),
+                                    _ptr(flow_a, flow_a_off), ld_a, _ptr(flow_b, flow_b_off), ld_b, fmt_b, _stream()),
            "vfml_coords_update")
 
 

@@ -78,9 +78,9 @@ class MOFNetHIP(_Holder):
             leaf = self._param(name)
             w = leaf.weight.detach().to(device=device, dtype=torch.float32)
             if name.endswith(".encoder.convc1"):
-                # each direction's lookup block is padded to a multiple of 4 channels (zero weights)
+                # each direction's lookup block is padded to whole float4s / split-row units (zero weights)
                 cor = cin // 2
-                cor_p = (cor + 3) // 4 * 4
+                cor_p = (cor + 7) // 8 * 8 if split else (cor + 3) // 4 * 4
                 wp = torch.zeros(cout, 2 * cor_p, 1, 1, device=device)
                 wp[:, :cor] = w[:, :cor]
                 wp[:, cor_p:cor_p + cor] = w[:, cor:]
@@ -127,7 +127,7 @@ class MOFNetHIP(_Holder):
         self._feat_cache.clear()
 
     # ------------------------------------------------------------------ encoder
-    def _encoder(self, prefix, x, n, H, W, P, dev, out, ldo, out_off, epilogue, split):
+    def _encoder(self, prefix, x, n, H, W, P, dev, out, ldo, out_off, epilogue, split, out_fmt=hip.FMT_F32):
         """RAFT BasicEncoder on NHWC4 input x [n,H,W,4]; writes [n,H/8,W/8,256] into `out`."""
         h2, w2 = H // 2, W // 2
         big = n * h2 * w2 * 64
@@ -174,7 +174,7 @@ class MOFNetHIP(_Holder):
                 ch, hh, ww = planes, ho, wo
         wgt, b = P[f"{prefix}.conv2"]
         hip.conv2d(cur, 128, 128, n, hh, ww, wgt, b, 256, 1, 1, out, ldo, out_off=out_off, epilogue=epilogue,
-                   split=split)
+                   split=split, out_fmt=out_fmt)
         return hh, ww
 
     # ------------------------------------------------------------------ forward
@@ -261,7 +261,12 @@ class MOFNetHIP(_Holder):
                     f = levels[l][i * Sl[l] * D:(i + 1) * Sl[l] * D]
                     # features are O(1): x16 keeps the lo halves of the split normal
                     tg.append(hip.SplitWeight(Sl[l], D, dev).fill(f, scale=16.0) if split else f)
-                ent = (fmap[i * Pn * D:(i + 1) * Pn * D], tg)
+                fm = fmap[i * Pn * D:(i + 1) * Pn * D]
+                if split:   # the GEMM's A operand in split rows, made once per frame
+                    fm16 = torch.empty(Pn * D, device=dev)
+                    hip.to_s16(fm, Pn, D, D, fm16, D)
+                    fm = fm16
+                ent = (fm, tg)
                 out[j] = ent
                 if keys is not None:
                     self._cache_put("f", keys[j], ent)
@@ -282,7 +287,8 @@ class MOFNetHIP(_Holder):
             hip.frames_to_nhwc4(src.index_select(0, torch.tensor(todo, device=dev)).contiguous(), m, H, W,
                                 float(self.cfg.input_scale), float(self.cfg.input_shift), frames)
             ctx = torch.empty(m * Pn * 256, device=dev)
-            self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim)
+            self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim,
+                          out_fmt=hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32)
             for i, j in enumerate(todo):
                 out[j] = ctx[i * Pn * 256:(i + 1) * Pn * 256]
                 if keys is not None:
@@ -306,7 +312,8 @@ class MOFNetHIP(_Holder):
         P = self._pack(dev)
         win = (2 * R + 1) ** 2
         cor = L * win
-        cor_p = (cor + 3) // 4 * 4   # per-direction channel block, 16-byte aligned
+        AF = hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32   # update-block activations
+        cor_p = (cor + 7) // 8 * 8 if AF == hip.FMT_S16 else (cor + 3) // 4 * 4   # per-direction channel block
 
         with torch.cuda.device(dev):
             hl, wl = [h], [w]
@@ -330,7 +337,7 @@ class MOFNetHIP(_Holder):
                 for d, tgt in (("f", c + 1), ("b", c - 1)):
                     for l in range(L):
                         hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[d][l],
-                                   ldl[l], out_off=(c - 1) * Pn * ldl[l], out_scale=scale)
+                                   ldl[l], out_off=(c - 1) * Pn * ldl[l], out_scale=scale, in_fmt=AF)
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
             # (one allocation, so that cat([r*h, x]) and cat([h, x]) are channel slices of it)
@@ -352,58 +359,62 @@ class MOFNetHIP(_Holder):
             coords1 = self._buf("coords1", MP * 4, dev)
 
             hip.coords_init(coords1, M, h, w)
-            hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124)
+            hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
+                              fmt_b=AF)
             ub = "update_block"
             for it in range(cfg.decoder_depth):
                 # K5
-                hip.corr_lookup(pyr["f"], hl, wl, ldl, R, MP, coords1, 0, 4, corr, 0, 2 * cor_p)
-                hip.corr_lookup(pyr["b"], hl, wl, ldl, R, MP, coords1, 2, 4, corr, cor_p, 2 * cor_p)
+                hip.corr_lookup(pyr["f"], hl, wl, ldl, R, MP, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF)
+                hip.corr_lookup(pyr["b"], hl, wl, ldl, R, MP, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF)
                 # motion encoder
                 wgt, b = P[f"{ub}.encoder.convc1"]
-                hip.conv2d(corr, 2 * cor_p, 2 * cor_p, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU)
+                hip.conv2d(corr, 2 * cor_p, 2 * cor_p, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
+                           in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convc2"]
-                hip.conv2d(c1, 256, 256, M, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU)
+                hip.conv2d(c1, 256, 256, M, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+                           in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convf1"]
-                hip.conv2d(flow4, 4, 4, M, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU)
+                hip.conv2d(flow4, 4, 4, M, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                           out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convf2"]
                 hip.conv2d(f1, 128, 128, M, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.conv"]
                 hip.conv2d(cf, 256, 256, M, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # temporal stack fusion: 3x1 conv along the frame axis of the motion features
                 wgt, b = P[f"{ub}.tprop"]
                 hip.conv2d(G, 128, GLD, 1, M, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
-                           epilogue=hip.EPI_RELU)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # SepConvGRU, horizontal then vertical
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, b = P[f"{ub}.gru.convzr{k}"]
                     # [z | r*h] = gates(conv([h | x]))
                     hip.conv2d(G, 512, GLD, M, h, w, wgt, b, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
                                pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_GRU_ZR, split=128,
-                               aux0=G, ld_aux0=GLD, aux0_off=HH)
+                               aux0=G, ld_aux0=GLD, aux0_off=HH, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                     wgt, b = P[f"{ub}.gru.convq{k}"]
                     # h = (1 - z) h + z tanh(conv([r*h | x])), in place
                     hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
                                in1=G, c1=384, ld1=GLD, in1_off=INP, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
-                               aux1=G, ld_aux1=GLD, aux1_off=HH)
+                               aux1=G, ld_aux1=GLD, aux1_off=HH, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                 # flow head
                 wgt, b = P[f"{ub}.flow_head.conv1"]
                 hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.flow_head.conv2"]
-                hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1)
+                hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
                 hip.coords_update(coords1, delta, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
-                                  flow_b_off=MF + 124)
+                                  flow_b_off=MF + 124, fmt_b=AF)
 
             # mask head on the final hidden state, then K8 for every flow of the output tensor
             mask = self._buf("mask", MP * 1152, dev)
             wgt, b = P[f"{ub}.mask.0"]
             hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                       epilogue=hip.EPI_RELU)
+                       epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
             wgt, b = P[f"{ub}.mask.2"]
-            hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25)
+            hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF)
             up = torch.empty(2 * M, H, W, 2, device=dev, dtype=torch.float32)
             upf = up.view(-1)
             for d in range(2):
