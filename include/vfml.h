@@ -26,9 +26,9 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 2
+#define VFML_ABI_VERSION 4
 
-/* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + bias[c]). */
+/* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
   VFML_EPI_NONE = 0,       /* out = v                                                        */
   VFML_EPI_RELU = 1,       /* out = max(v, 0)                                                */
@@ -66,6 +66,10 @@ typedef struct vfml_conv_desc {
   int32_t epilogue; int32_t split; float out_scale;
   const float* aux0; int32_t ld_aux0;
   const float* aux1; int32_t ld_aux1;
+  const float* addend; int32_t ld_addend;           /* optional f32 map [pixels][ld_addend] added to the
+                                                       accumulator before bias/epilogue (a per-pixel bias:
+                                                       the part of a convolution whose input does not
+                                                       change between calls, computed once)             */
 } vfml_conv_desc;
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
@@ -112,15 +116,17 @@ int vfml_instnorm_apply(const float* x, const float* stats, const float* res,
  * features (avg-pool commutes with the dot product). */
 int vfml_avgpool2x2(const float* x, int n, int h, int w, int c, float* out, void* stream);
 
-/* K5: correlation lookup.  For each of nq queries (row q of every pyramid level) sample a
- * (2r+1)^2 window around coords[q]/2^l with bilinear interpolation, zeros outside, RAFT's
- * window order (channel i*(2r+1)+j samples x+d[i], y+d[j]).
- *   pyr[l]     : float [nq][ld[l]]  (row = query, columns = hl[l]*wl[l] targets, row-major)
- *   coords     : float [nq][ld_coords], x at +0, y at +1
- *   out        : float [nq][ld_out], levels*(2r+1)^2 channels written from out
+/* K5: correlation lookup.  nmaps query maps (correlation problems) of q_per_map queries each; query q
+ * of map m reads row q of that map's pyramid.  For each query sample a (2r+1)^2 window around
+ * coords/2^l with bilinear interpolation, zeros outside, RAFT's window order (channel i*(2r+1)+j
+ * samples x+d[i], y+d[j]).
+ *   pyr[m*levels+l] : float [q_per_map][ld[l]]  (columns = hl[l]*wl[l] targets, row-major); host array
+ *                     of device pointers - each problem's pyramid may live in its own allocation
+ *   coords          : float [nmaps*q_per_map][ld_coords], x at +0, y at +1
+ *   out             : [nmaps*q_per_map][ld_out], levels*(2r+1)^2 channels written from out
  * Replaces: F.grid_sample(align_corners=True) x levels. */
 int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl,
-                     const int32_t* ld, int levels, int radius, int nq,
+                     const int32_t* ld, int levels, int radius, int nmaps, int q_per_map,
                      const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, void* stream);
 /* out_fmt VFML_FMT_S16: channels are written as split rows; the channel count is rounded up to a
  * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0). */

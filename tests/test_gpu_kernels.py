@@ -347,6 +347,24 @@ def test_corr_lookup_matches_grid_sample(gpu, radius, levels):
     assert (got - ref).abs().max().item() < 2e-5
 
 
+def test_corr_lookup_several_maps_in_separate_allocations(gpu):
+    """Each query map (correlation problem) brings its own pyramid allocation; rows are map-major."""
+    from vfml import hip
+    h, w, r = 12, 16, 2
+    P = h * w
+    g = torch.Generator().manual_seed(31)
+    maps = [[torch.randn(P, P, generator=g).cuda().reshape(-1), torch.randn(P, P // 4, generator=g).cuda().reshape(-1)]
+            for _ in range(3)]
+    coords = (torch.rand(3 * P, 4, generator=g) * torch.tensor([w, h, w, h])).cuda().reshape(-1)
+    hl, wl, ld = [h, h // 2], [w, w // 2], [P, P // 4]
+    together = torch.empty(3 * P * 50, device=gpu)
+    hip.corr_lookup(maps, hl, wl, ld, r, P, coords, 0, 4, together, 0, 50)
+    for m in range(3):
+        alone = torch.empty(P * 50, device=gpu)
+        hip.corr_lookup(maps[m], hl, wl, ld, r, P, coords, m * P * 4, 4, alone, 0, 50)
+        assert torch.equal(together.view(3, P, 50)[m], alone.view(P, 50))
+
+
 def test_corr_lookup_integer_coords_is_exact_gather(gpu):
     """Known answer: at integer coordinates the window is a plain gather, zeros outside."""
     from vfml import hip

@@ -25,9 +25,9 @@ constexpr int KG = BK / 4;  // float4 k-groups per K step
 struct ConvArgs {
   const float* in0; const float* in1;
   const float* weight; const float* bias;
-  const float* aux0; const float* aux1;
+  const float* aux0; const float* aux1; const float* addend;
   float* out;
-  int c0, ld0, c1, ld1, ctot;
+  int c0, ld0, c1, ld1, ctot, ld_addend;
   int H, W, ho, wo;
   int kw, stride, pad_h, pad_w;
   int M, K, cout;
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (row >= a.M) continue;
-        float v = (acc[i][j][e] + bias) * a.out_scale;
+        float v = acc[i][j][e];
+        if (a.addend) v += a.addend[(int64_t)row * a.ld_addend + col];
+        v = (v + bias) * a.out_scale;
         switch (a.epilogue) {
           case VFML_EPI_RELU: v = fmaxf(v, 0.f); break;
           case VFML_EPI_TANH: v = tanhf(v); break;
@@ -261,6 +263,8 @@ extern "C" int vfml_conv2d(const vfml_conv_desc* d, void* stream) {
   ConvArgs a;
   a.in0 = d->in0; a.in1 = two ? d->in1 : d->in0;
   a.weight = d->weight; a.bias = d->bias; a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
+  a.addend = d->addend; a.ld_addend = d->ld_addend;
+  VFML_REQUIRE(!d->addend || d->ld_addend >= d->cout, "vfml_conv2d: ld_addend=%d < cout", d->ld_addend);
   a.c0 = d->c0; a.ld0 = d->ld0; a.c1 = d->c1; a.ld1 = two ? d->ld1 : d->ld0; a.ctot = d->c0 + d->c1;
   a.H = d->h; a.W = d->w; a.ho = ho; a.wo = wo;
   a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;

@@ -51,9 +51,9 @@ constexpr int OOB = 0x7fffffff;   // >= any num_records we create (all < 2^31 by
 struct SplitArgs {
   const float* in0; const float* in1;
   const _Float16* whi; const _Float16* wlo; const float* bias;
-  const float* aux0; const float* aux1;
+  const float* aux0; const float* aux1; const float* addend;
   float* out;
-  int c0, ld0, c1, ld1, ctot;
+  int c0, ld0, c1, ld1, ctot, ld_addend;
   int H, W, ho, wo;
   int kh, kw, stride, pad_h, pad_w;
   int M, K, Kp, cout;
@@ -404,8 +404,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void conv_gemm_split_ker
       const bool lowhalf = col < a.split;   // split is a multiple of 4: a quad never straddles it
       const int nvalid = a.cout - col >= 4 ? 4 : a.cout - col;
       f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4 * q]);
+      f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.addend) {
+        if (nvalid == 4 && a.vec_ok) {
+          add4 = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + col);
+        } else {
+          for (int e = 0; e < nvalid; ++e) add4[e] = a.addend[(int64_t)grow * a.ld_addend + col + e];
+        }
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + bias4[q][e]) * a.out_scale;
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + add4[e] + bias4[q][e]) * a.out_scale;
       f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
       if (nvalid == 4) {
         if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0 = aux4(a.aux0, a.ld_aux0, grow, col - a.split);
@@ -585,6 +593,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   a.bytes0 = (int)((e0 > e1 ? e0 : e1) * 4);
   a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo; a.bias = d->bias;
   a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
+  a.addend = d->addend; a.ld_addend = d->ld_addend;
   a.c0 = d->c0; a.ld0 = d->ld0; a.c1 = d->c1; a.ld1 = two ? d->ld1 : d->ld0; a.ctot = d->c0 + d->c1;
   a.H = d->h; a.W = d->w; a.ho = ho; a.wo = wo;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
@@ -596,7 +605,9 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   a.mtiles = (a.M + BM - 1) / BM;
   a.vec_ok = vfml_aligned16(d->out) && d->ldo % 4 == 0 &&
              (!d->aux0 || (vfml_aligned16(d->aux0) && d->ld_aux0 % 4 == 0)) &&
-             (!d->aux1 || (vfml_aligned16(d->aux1) && d->ld_aux1 % 4 == 0));
+             (!d->aux1 || (vfml_aligned16(d->aux1) && d->ld_aux1 % 4 == 0)) &&
+             (!d->addend || (vfml_aligned16(d->addend) && d->ld_addend % 4 == 0));
+  VFML_REQUIRE(!d->addend || d->ld_addend >= d->cout, "vfml_conv2d_split: ld_addend=%d < cout", d->ld_addend);
   a.out16 = out_fmt == VFML_FMT_S16;
   a.aux16 = aux_fmt == VFML_FMT_S16;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -6,14 +6,15 @@
 namespace {
 
 constexpr int MAX_LEVELS = 6;
+constexpr int MAX_MAPS = 8;
 constexpr int MAX_RADIUS = 4;
 constexpr int PATCH = 2 * MAX_RADIUS + 2;  // 10 integer-grid samples per axis
 constexpr int LOOKUP_WAVES = 4;
 
 struct LookupArgs {
-  const float* pyr[MAX_LEVELS];
+  const float* pyr[MAX_MAPS][MAX_LEVELS];   // one pyramid per query map (problem); rows = that map's queries
   int hl[MAX_LEVELS], wl[MAX_LEVELS], ld[MAX_LEVELS];
-  int levels, radius, nq;
+  int levels, radius, nq, q_per_map;
   const float* coords; int ld_coords;
   float* out; int ld_out;
   int out16;
@@ -30,6 +31,8 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
   const int wv = threadIdx.x >> 6;
   const int q = blockIdx.x * LOOKUP_WAVES + wv;
   const bool live = q < a.nq;
+  const int map = live ? q / a.q_per_map : 0;
+  const int qq = q - map * a.q_per_map;      // row inside that map's pyramid
   const int side = 2 * a.radius + 2;  // patch side
   const int win = 2 * a.radius + 1;
   const int psz = side * side;
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
       const int xx = x0 + px, yy = y0 + py;
       float v = 0.f;
       if (xx >= 0 && xx < a.wl[l] && yy >= 0 && yy < a.hl[l])
-        v = a.pyr[l][(int64_t)q * a.ld[l] + (int64_t)yy * a.wl[l] + xx];
+        v = a.pyr[map][l][(int64_t)qq * a.ld[l] + (int64_t)yy * a.wl[l] + xx];
       patch[wv][l][idx] = v;
       if (idx == 0) {
         frac[wv][l][0] = x - fx0;
@@ -185,13 +188,15 @@ inline int grid_for(int64_t items, int block) {
 }  // namespace
 
 extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
-                                int levels, int radius, int nq, const float* coords, int ld_coords, float* out,
-                                int ld_out, int out_fmt, void* stream) {
+                                int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
+                                float* out, int ld_out, int out_fmt, void* stream) {
+  VFML_REQUIRE(nmaps >= 1 && nmaps <= MAX_MAPS && q_per_map > 0, "vfml_corr_lookup: nmaps=%d out of [1,%d] or empty maps", nmaps, MAX_MAPS);
+  const int nq = nmaps * q_per_map;
   VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
   VFML_REQUIRE(pyr && hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
   VFML_REQUIRE(levels >= 1 && levels <= MAX_LEVELS, "vfml_corr_lookup: levels=%d out of [1,%d]", levels, MAX_LEVELS);
   VFML_REQUIRE(radius >= 1 && radius <= MAX_RADIUS, "vfml_corr_lookup: radius=%d out of [1,%d]", radius, MAX_RADIUS);
-  VFML_REQUIRE(nq > 0 && ld_coords >= 2, "vfml_corr_lookup: bad nq/ld_coords");
+  VFML_REQUIRE(ld_coords >= 2, "vfml_corr_lookup: bad ld_coords");
   const int nout = levels * (2 * radius + 1) * (2 * radius + 1);
   VFML_REQUIRE(ld_out >= nout, "vfml_corr_lookup: ld_out=%d < %d channels", ld_out, nout);
   if (out_fmt == VFML_FMT_S16)
@@ -199,12 +204,18 @@ extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, cons
                  "vfml_corr_lookup: split-row output needs a 32-byte aligned out and ld_out %% 8 == 0");
   LookupArgs a;
   a.out16 = out_fmt == VFML_FMT_S16;
+  for (int m = 0; m < MAX_MAPS; ++m)
+    for (int l = 0; l < MAX_LEVELS; ++l) a.pyr[m][l] = nullptr;
   for (int l = 0; l < levels; ++l) {
-    VFML_REQUIRE(pyr[l] && hl[l] > 0 && wl[l] > 0 && ld[l] >= hl[l] * wl[l], "vfml_corr_lookup: bad level %d", l);
-    a.pyr[l] = pyr[l]; a.hl[l] = hl[l]; a.wl[l] = wl[l]; a.ld[l] = ld[l];
+    VFML_REQUIRE(hl[l] > 0 && wl[l] > 0 && ld[l] >= hl[l] * wl[l], "vfml_corr_lookup: bad level %d", l);
+    a.hl[l] = hl[l]; a.wl[l] = wl[l]; a.ld[l] = ld[l];
+    for (int m = 0; m < nmaps; ++m) {
+      VFML_REQUIRE(pyr[m * levels + l], "vfml_corr_lookup: null pyramid pointer (map %d, level %d)", m, l);
+      a.pyr[m][l] = pyr[m * levels + l];
+    }
   }
-  for (int l = levels; l < MAX_LEVELS; ++l) { a.pyr[l] = nullptr; a.hl[l] = a.wl[l] = a.ld[l] = 0; }
-  a.levels = levels; a.radius = radius; a.nq = nq;
+  for (int l = levels; l < MAX_LEVELS; ++l) a.hl[l] = a.wl[l] = a.ld[l] = 0;
+  a.levels = levels; a.radius = radius; a.nq = nq; a.q_per_map = q_per_map;
   a.coords = coords; a.ld_coords = ld_coords; a.out = out; a.ld_out = ld_out;
   hipLaunchKernelGGL(corr_lookup_kernel, dim3((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), dim3(64 * LOOKUP_WAVES), 0,
                      reinterpret_cast<hipStream_t>(stream), a);

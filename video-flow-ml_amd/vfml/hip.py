@@ -33,6 +33,7 @@ class ConvDesc(ctypes.Structure):
         ("epilogue", c_int32), ("split", c_int32), ("out_scale", c_float),
         ("aux0", c_void_p), ("ld_aux0", c_int32),
         ("aux1", c_void_p), ("ld_aux1", c_int32),
+        ("addend", c_void_p), ("ld_addend", c_int32),
     ]
 
 
@@ -77,14 +78,14 @@ def lib():
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                   c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
+                                   c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 2:
+    if L.vfml_abi_version() != 4:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -181,7 +182,7 @@ class SplitWeight:
 def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, stride=1, pad_h=0, pad_w=0,
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
-           in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32):
+           in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers)."""
     d = ConvDesc()
@@ -196,6 +197,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.epilogue, d.split, d.out_scale = epilogue, split, out_scale
     d.aux0, d.ld_aux0 = (_ptr(_dev(aux0), aux0_off) if aux0 is not None else None), ld_aux0
     d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
+    d.addend, d.ld_addend = (_ptr(_dev(addend), addend_off) if addend is not None else None), ld_addend
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
         def launch():
@@ -258,14 +260,17 @@ def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):
            "vfml_to_s16")
 
 
-def corr_lookup(pyr, hl, wl, ld, radius, nq, coords, coords_off, ld_coords, out, out_off, ld_out, row_off=0,
+def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coords, out, out_off, ld_out,
                 out_fmt=FMT_F32):
-    """pyr: list of flat float32 device tensors (one per level); row_off: first query row inside each level."""
-    L = len(pyr)
-    ptrs = (c_void_p * L)(*[p.data_ptr() + 4 * row_off * ld[i] for i, p in enumerate(pyr)])
-    _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius, nq,
-                                  _ptr(_dev(coords), coords_off), ld_coords, _ptr(_dev(out), out_off), ld_out,
-                                  out_fmt, _stream()), "vfml_corr_lookup")
+    """pyrs: list (one entry per query map) of lists (one flat float32 device tensor per level, rows =
+    that map's q_per_map queries).  Queries / coords / out rows are ordered map-major."""
+    if pyrs and torch.is_tensor(pyrs[0]):
+        pyrs = [pyrs]
+    nmaps, L = len(pyrs), len(pyrs[0])
+    ptrs = (c_void_p * (nmaps * L))(*[p.data_ptr() for m in pyrs for p in m])
+    _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
+                                  nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
+                                  _ptr(_dev(out), out_off), ld_out, out_fmt, _stream()), "vfml_corr_lookup")
 
 
 def coords_init(coords1, n, h, w):

@@ -90,16 +90,31 @@ class MOFNetHIP(_Holder):
                 w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None),
                        leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous())
-        # z and r gates share their input: one conv with 2*hidden outputs per GRU pass
+        # GRU gates.  Input channels are [h | inp | motion | temporal]; `inp` (the context map) does not
+        # change over the iterations, so its part of every gate convolution (+ bias) is computed once per
+        # frame and added in the epilogue ("addend"); the per-iteration convolutions see [h | motion |
+        # temporal] only (K 2560 -> 1920).  z and r share their input: one conv with 2*hidden outputs.
+        hid = self.hidden_dim
+        self._cout_of = {}
         for k in ("1", "2"):
-            wz, bz = P[f"update_block.gru.convz{k}"]
-            wr, br = P[f"update_block.gru.convr{k}"]
-            P[f"update_block.gru.convzr{k}"] = (torch.cat([wz, wr]).contiguous(), torch.cat([bz, br]).contiguous())
+            self._cout_of[f"update_block.gru.convzr{k}.iter"] = 2 * hid
+            self._cout_of[f"update_block.gru.convq{k}.iter"] = hid
+            raw = {g: self._param(f"update_block.gru.conv{g}{k}") for g in "zrq"}
+            wzr = torch.cat([raw["z"].weight, raw["r"].weight]).detach().to(device=device, dtype=torch.float32)
+            bzr = torch.cat([raw["z"].bias, raw["r"].bias]).detach().to(device=device, dtype=torch.float32)
+            wq = raw["q"].weight.detach().to(device=device, dtype=torch.float32)
+            bq = raw["q"].bias.detach().to(device=device, dtype=torch.float32)
+            for nm, wfull, bfull in ((f"update_block.gru.convzr{k}", wzr, bzr), (f"update_block.gru.convq{k}", wq, bq)):
+                it = torch.cat([wfull[:, :hid], wfull[:, 2 * hid:]], dim=1)
+                P[nm + ".iter"] = (pack_conv_weight(it), None)
+                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid]), bfull.contiguous())
+            for g in "zrq":
+                del P[f"update_block.gru.conv{g}{k}"]
         if split:
             # split-f16 planes (hi, lo*2^11) of every [cout][K] matrix, made once per load
             with torch.cuda.device(device):
                 for name, (wflat, b) in list(P.items()):
-                    cout = b.numel()
+                    cout = self._cout_of[name] if name in self._cout_of else b.numel()
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
                     P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
         self._packed, self._packed_key = P, key
@@ -224,9 +239,9 @@ class MOFNetHIP(_Holder):
             self._feat_cache.move_to_end((kind, key))
         return ent
 
-    def _cache_put(self, kind, key, value):
+    def _cache_put(self, kind, key, value, limit=None):
         self._feat_cache[(kind, key)] = value
-        while sum(1 for k in self._feat_cache if k[0] == kind) > self.FEATURE_CACHE_FRAMES:
+        while sum(1 for k in self._feat_cache if k[0] == kind) > (limit or self.FEATURE_CACHE_FRAMES):
             oldest = next(k for k in self._feat_cache if k[0] == kind)
             del self._feat_cache[oldest]
 
@@ -287,10 +302,21 @@ class MOFNetHIP(_Holder):
             hip.frames_to_nhwc4(src.index_select(0, torch.tensor(todo, device=dev)).contiguous(), m, H, W,
                                 float(self.cfg.input_scale), float(self.cfg.input_shift), frames)
             ctx = torch.empty(m * Pn * 256, device=dev)
-            self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim,
-                          out_fmt=hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32)
+            AF = hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32
+            self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim, out_fmt=AF)
+            h8, w8 = H // 8, W // 8
             for i, j in enumerate(todo):
-                out[j] = ctx[i * Pn * 256:(i + 1) * Pn * 256]
+                cx = ctx[i * Pn * 256:(i + 1) * Pn * 256]
+                # context part of the GRU gate convolutions (+ bias), per pass: [z|r] (256) and q (128)
+                add = {}
+                for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+                    for g, co in (("zr", 256), ("q", 128)):
+                        wgt, b = P[f"update_block.gru.conv{g}{k}.ctx"]
+                        a = torch.empty(Pn * co, device=dev)
+                        hip.conv2d(cx, 128, 256, 1, h8, w8, wgt, b, co, kh, kw, a, co, in0_off=128,
+                                   pad_h=kh // 2, pad_w=kw // 2, in_fmt=AF)
+                        add[g + k] = a
+                out[j] = (cx, add)
                 if keys is not None:
                     self._cache_put("c", keys[j], out[j])
         return out
@@ -329,15 +355,27 @@ class MOFNetHIP(_Holder):
             # K1 + K2: feature maps and pooled target pyramids, per frame (cached across windows)
             feats = self._frame_features(src, list(range(N)), keys, H, W, P, dev, L, hl, wl, Sl)
 
-            # K3/K4 correlation pyramids: rows = (centre frame, query cell); level l is one GEMM of the
-            # centre frame's features against the 2^l-pooled features of the neighbour frame
-            pyr = {d: [self._buf(f"pyr_{d}{l}", MP * ldl[l], dev) for l in range(L)] for d in ("f", "b")}
+            # K3/K4 correlation pyramids, one per problem (query frame -> target frame): level l is one
+            # GEMM of the query frame's features against the 2^l-pooled features of the target frame.
+            # A pyramid depends on its two frames only, so with frame keys it is kept across windows:
+            # consecutive sliding windows share 2(N-3) of their 2(N-2) problems.
             scale = 1.0 / float(D) ** 0.5
+            pyrs = {"f": [], "b": []}
             for c in range(1, N - 1):
                 for d, tgt in (("f", c + 1), ("b", c - 1)):
-                    for l in range(L):
-                        hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[d][l],
-                                   ldl[l], out_off=(c - 1) * Pn * ldl[l], out_scale=scale, in_fmt=AF)
+                    pk = ("p", keys[c], keys[tgt]) if keys is not None else None
+                    pyr = self._cache_get("p", pk) if pk is not None else None
+                    if pyr is None:
+                        if pk is None:    # uncached call: reuse one workspace set per problem slot
+                            pyr = [self._buf(f"pyr_{d}{c}_{l}", Pn * ldl[l], dev) for l in range(L)]
+                        else:
+                            pyr = [torch.empty(Pn * ldl[l], device=dev) for l in range(L)]
+                        for l in range(L):
+                            hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[l],
+                                       ldl[l], out_scale=scale, in_fmt=AF)
+                        if pk is not None:
+                            self._cache_put("p", pk, pyr, limit=2 * (N - 2) + 2)
+                    pyrs[d].append(pyr)
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
             # (one allocation, so that cat([r*h, x]) and cat([h, x]) are channel slices of it)
@@ -346,8 +384,13 @@ class MOFNetHIP(_Holder):
             # K2 context encoder on the centre frames -> h = tanh(first half), inp = relu(second half)
             ctx = self._frame_context(src, list(range(1, N - 1)), keys, H, W, P, dev, Pn)
             Gv = G.view(MP, GLD)
+            gate_add = {g + k: self._buf(f"gate_add_{g}{k}", MP * co, dev)
+                        for k in ("1", "2") for g, co in (("zr", 256), ("q", 128))}
             for c in range(1, N - 1):
-                Gv[(c - 1) * Pn:c * Pn, HH:HH + 256].copy_(ctx[c].view(Pn, 256))
+                Gv[(c - 1) * Pn:c * Pn, HH:HH + 256].copy_(ctx[c][0].view(Pn, 256))
+                for name, buf in gate_add.items():
+                    n_el = ctx[c][1][name].numel()
+                    buf[(c - 1) * n_el:c * n_el].copy_(ctx[c][1][name])
 
             corr = self._buf("corr", MP * 2 * cor_p, dev, zero=True)   # pad channels stay zero
             c1 = self._buf("c1", MP * 256, dev)
@@ -364,8 +407,8 @@ class MOFNetHIP(_Holder):
             ub = "update_block"
             for it in range(cfg.decoder_depth):
                 # K5
-                hip.corr_lookup(pyr["f"], hl, wl, ldl, R, MP, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF)
-                hip.corr_lookup(pyr["b"], hl, wl, ldl, R, MP, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF)
+                hip.corr_lookup(pyrs["f"], hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF)
+                hip.corr_lookup(pyrs["b"], hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF)
                 # motion encoder
                 wgt, b = P[f"{ub}.encoder.convc1"]
                 hip.conv2d(corr, 2 * cor_p, 2 * cor_p, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
@@ -388,17 +431,19 @@ class MOFNetHIP(_Holder):
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # SepConvGRU, horizontal then vertical
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
-                    wgt, b = P[f"{ub}.gru.convzr{k}"]
-                    # [z | r*h] = gates(conv([h | x]))
-                    hip.conv2d(G, 512, GLD, M, h, w, wgt, b, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
-                               pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_GRU_ZR, split=128,
-                               aux0=G, ld_aux0=GLD, aux0_off=HH, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
-                    wgt, b = P[f"{ub}.gru.convq{k}"]
-                    # h = (1 - z) h + z tanh(conv([r*h | x])), in place
-                    hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
-                               in1=G, c1=384, ld1=GLD, in1_off=INP, pad_h=kh // 2, pad_w=kw // 2,
+                    wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
+                    # [z | r*h] = gates(conv([h | motion | temporal]) + context part)
+                    hip.conv2d(G, 128, GLD, M, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
+                               in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
+                               epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
+                               addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                    wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
+                    # h = (1 - z) h + z tanh(conv([r*h | motion | temporal]) + context part), in place
+                    hip.conv2d(G, 128, GLD, M, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
+                               in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
-                               aux1=G, ld_aux1=GLD, aux1_off=HH, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                               aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
+                               in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                 # flow head
                 wgt, b = P[f"{ub}.flow_head.conv1"]
                 hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
