@@ -35,7 +35,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.vfml_conv2d(ctypes.byref(d), None) != 0
     assert b"null" in L.vfml_last_error()
     assert L.vfml_conv2d(None, None) != 0
-    assert L.vfml_instnorm_workspace_bytes(2, 4096 * 3 + 1, 64) == 2 * 4 * 64 * 2 * 8
+    assert L.vfml_instnorm_workspace_bytes(2, 1024 * 3 + 1, 64) == 2 * 4 * 64 * 2 * 8
     assert L.vfml_corr_lookup(None, None, None, None, 4, 4, 1, 1, None, 4, None, 324, 0, None) != 0
 
 

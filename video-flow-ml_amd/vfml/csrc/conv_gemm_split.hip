@@ -612,25 +612,36 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   a.aux16 = aux_fmt == VFML_FMT_S16;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool bigc = a.ctot >= BK;
+  // Tile width: 128 columns per workgroup unless 64-wide tiles use the machine better.  Efficiency
+  // model = (useful columns / padded columns) x (workgroups / slots of the last partial round) x a
+  // 0.7 handicap for the narrower tile (half the MFMAs per loaded A element; measured: 64-wide tiles lose more than the tail round gains on the 1080p shapes); 2 workgroups per CU.
+  int bn = d->cout > 64 ? 128 : (d->cout > 32 ? 64 : 32);
+  if (d->cout > 64) {
+    auto eff = [&](int w) {
+      const int nt = (d->cout + w - 1) / w;
+      const int64_t wg = (int64_t)a.mtiles * nt, slots = 512;
+      const int64_t rounds = (wg + slots - 1) / slots;
+      return ((double)d->cout / (nt * w)) * ((double)wg / (rounds * slots)) * (w == 64 ? 0.7 : 1.0);
+    };
+    static const int force = getenv("VFML_BN") ? atoi(getenv("VFML_BN")) : 0;
+    if (force == 64 || (force == 0 && eff(64) > eff(128))) bn = 64;
+  }
   if (in16) {   // split-row sources: every slice is a multiple of 8 channels and >= one K step wide
-    if (d->cout > 64) {
+    if (bn == 128) {
       a.ntiles = (d->cout + 127) / 128;
-      static const int waves8 = getenv("VFML_WAVES8") ? atoi(getenv("VFML_WAVES8")) : 0;
-      if (waves8 == 1) return launch<128, 4, 2, true, true>(a, s);
-      if (waves8 == 2) return launch<128, 2, 4, true, true>(a, s);
       return launch<128, 2, 2, true, true>(a, s);
-    } else if (d->cout > 32) {
-      a.ntiles = 1;
+    } else if (bn == 64) {
+      a.ntiles = (d->cout + 63) / 64;
       return launch<64, 2, 2, true, true>(a, s);
     }
     a.ntiles = 1;
     return launch<32, 4, 1, true, true>(a, s);
   }
-  if (d->cout > 64) {
+  if (bn == 128) {
     a.ntiles = (d->cout + 127) / 128;
     return bigc ? launch<128, 2, 2, true, false>(a, s) : launch<128, 2, 2, false, false>(a, s);
-  } else if (d->cout > 32) {
-    a.ntiles = 1;
+  } else if (bn == 64) {
+    a.ntiles = (d->cout + 63) / 64;
     return bigc ? launch<64, 2, 2, true, false>(a, s) : launch<64, 2, 2, false, false>(a, s);
   }
   a.ntiles = 1;

@@ -157,8 +157,11 @@ inline int grid_for(int64_t items, int block) {
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// Pixel chunks per image: ~1024 px each so that even one 540x960 frame (the steady state of the
+// sliding-window cache) spreads over >= 2 workgroups per CU; capped so pass 2 stays short.
 int stat_chunks(int hw) {
-  int chunks = (hw + 4095) / 4096;
+  int chunks = (hw + 1023) / 1024;
+  if (chunks > 1024) chunks = 1024;
   return chunks < 1 ? 1 : chunks;
 }
 

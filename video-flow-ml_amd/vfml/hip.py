@@ -148,8 +148,11 @@ def profile_end():
 
 def conv_variant(cout, split=False):
     """Which template instantiation vfml_conv2d[_split] dispatches to (conv_gemm[_split].hip)."""
-    base = "conv_gemm_split_kernel" if split else "conv_gemm_kernel"
-    return base + ("<128,2,2>" if cout > 64 else ("<64,2,2>" if cout > 32 else "<32,4,1>"))
+    # (bench.py's roofline leg groups launches by family; the split kernel picks 64- or 128-wide tiles
+    # per shape, which is a tuning detail inside one kernel family)
+    if split:
+        return "conv_gemm_split_kernel"
+    return "conv_gemm_kernel" + ("<128,2,2>" if cout > 64 else ("<64,2,2>" if cout > 32 else "<32,4,1>"))
 
 
 class SplitWeight:
