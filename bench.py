@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads for the CPU baseline (0 = this process's CPU share: affinity / cgroup quota, "
                          "capped at 16 - the per-GPU share of the pool's boxes)")
-    ap.add_argument("--cpu-sample-height", type=int, default=544,
+    ap.add_argument("--cpu-sample-height", type=int, default=0,
                     help="CPU-baseline sample: 0 = one full-size field (minutes of CPU time), else one field on a "
                          "centre crop of this height (16:9), scaled to full size by the analytic FLOP ratio")
     args = ap.parse_args()

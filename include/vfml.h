@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 4
+#define VFML_ABI_VERSION 5
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -37,6 +37,7 @@ enum {
   VFML_EPI_TANH_RELU = 4,  /* c <  split: tanh(v)   else relu(v)   (cnet -> net | inp)       */
   VFML_EPI_GRU_ZR = 5,     /* c <  split: sigmoid(v) else sigmoid(v) * aux0[p][c - split]    */
   VFML_EPI_GRU_Q = 6,      /* out = (1 - z) * h + z * tanh(v), z = aux0[p][c], h = aux1[p][c] */
+  VFML_EPI_ADD_AUX = 7,    /* out = aux0[p][c] + v   (residual / memory read-out: m + gamma*acc)   */
 };
 
 /* Activation storage formats.
@@ -92,6 +93,17 @@ int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, i
  * near 2^14 keeps the lo halves out of the f16 subnormal range. */
 int vfml_split_f16(const float* src, int64_t rows, int k, int ld, float scale, void* hi, void* lo, int kp,
                    void* stream);
+
+/* Row softmax: out[r][c] = exp(x[r][c] - max_r) / sum_r for c < cols, written as split rows
+ * (VFML_FMT_S16) and zero-filled up to ld_out (ld_out % 8 == 0, ld_out >= cols).  x: f32 [rows][ld_in].
+ * Replaces: torch.softmax over the key axis of the attention scores (materialised:
+ * with 288 GB of HBM the P x P score matrix of one frame simply stays resident). */
+int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out, void* stream);
+
+/* src f32 [rows][c] (row stride ld) -> split-f16 planes of its TRANSPOSE times scale: hi/lo [c][kp],
+ * kp >= rows, kp % 32 == 0, zero padded: the "weight" operand of out = attn . V. */
+int vfml_transpose_split_f16(const float* src, int rows, int c, int ld, float scale, void* hi, void* lo, int kp,
+                             void* stream);
 
 /* K1: frames -> normalised NHWC4 (4th channel zero):  dst = scale * x + shift.
  * kind 0: src is uint8 [n][H][W][3] (values 0..255, x = u8/255 as the reference does at

@@ -266,6 +266,9 @@ class MOFNetOracle(nn.Module):
     @torch.no_grad()
     def forward(self, images, data=None, return_lowres=False):
         cfg = self.cfg
+        if getattr(cfg, "network", "MOFNetStack") == "BOFNet" and images.shape[1] > 3:
+            lo = images.shape[1] // 2 - 1          # tri-frame member: centre triple of the window
+            images = images[:, lo:lo + 3]
         B, N, _, H, W = images.shape
         M = N - 2
         h, w = H // 8, W // 8

@@ -207,6 +207,48 @@ def main():
     z = np.load(os.path.join(d, "flow_frame_000001_lod2.npz"))
     J["lod_members"] = {k: {"dtype": str(z[k].dtype), "shape": list(z[k].shape)} for k in z.files}
 
+    # ---- MemFlow windows / tensors (processing/memflow_processor.py:97-139) and core checks -----------
+    with quiet:
+        from processing.memflow_processor import MemFlowProcessor
+        from processing.memflow_core import MemFlowCore
+    mw = []
+    for T in (1, 2, 3, 5):
+        with quiet:
+            mp_ = MemFlowProcessor("cpu", sequence_length=T)
+        fr = [np.full((64, 64, 3), i, np.uint8) for i in range(6)]
+        for i in range(6):
+            t = mp_.prepare_frame_sequence(list(fr), i)
+            mw.append({"T": T, "i": i, "idx": t[0, :, 0, 0, 0].long().tolist(), "shape": list(t.shape),
+                       "dtype": str(t.dtype), "device": str(t.device)})
+    J["memflow_windows"] = mw
+    J["memflow_tile_grid"] = list(mp_.calculate_tile_grid(1920, 1080))
+    merr = {}
+    with quiet:
+        mc = MemFlowCore("cpu")
+    for key, arg in (("type", np.zeros((1, 2, 3, 64, 64))), ("ndim", torch.zeros(2, 3, 64, 64)),
+                     ("batch", torch.zeros(2, 2, 3, 64, 64)), ("frames", torch.zeros(1, 1, 3, 64, 64)),
+                     ("channels", torch.zeros(1, 2, 4, 64, 64)), ("small", torch.zeros(1, 2, 3, 32, 64))):
+        try:
+            mc.validate_input_tensor(arg)
+        except Exception as e:
+            merr[key] = [type(e).__name__, str(e)]
+    try:
+        mc.compute_flow_from_tensor(torch.zeros(1, 2, 3, 64, 64))
+    except Exception as e:
+        merr["not_loaded"] = [type(e).__name__, str(e)]
+    try:
+        mc.load_model()
+    except Exception as e:
+        merr["missing"] = [type(e).__name__, str(e)]
+    for key, fr_ in (("empty", []), ("one", [np.zeros((64, 64, 3), np.uint8)]),
+                     ("small", [np.zeros((32, 64, 3), np.uint8)] * 2),
+                     ("mismatch", [np.zeros((64, 64, 3), np.uint8), np.zeros((64, 72, 3), np.uint8)])):
+        try:
+            mp_.validate_frame_sequence(fr_)
+        except Exception as e:
+            merr["seq_" + key] = [type(e).__name__, str(e)]
+    J["memflow_errors"] = merr
+
     # ---- CLI flag surface (flow_processor.py:1272-1332): names, defaults, choices — read from the
     # parser definition with the ast module (the file itself needs cv2 to import)
     import ast

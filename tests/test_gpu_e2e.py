@@ -55,6 +55,19 @@ def test_fast_mode_config_matches_oracle(gpu):
     assert _epe(got.cpu(), ref).mean().item() < EPE_TOL
 
 
+def test_bof_tri_frame_variant_matches_oracle(gpu):
+    """--vf-architecture bof (BASELINE config 5 shape: seq_len 9): the tri-frame network on the centre
+    triple of the window; output [1,2,2,H,W], the reference's index pick lands on the backward flow."""
+    net, ora = _pair(network="BOFNet")
+    x = torch.rand(1, 9, 3, 128, 160, generator=torch.Generator().manual_seed(7))
+    ref, _ = ora(x, {})
+    got, _ = net(x.cuda(), {})
+    assert got.shape == ref.shape == (1, 2, 2, 128, 160)
+    assert _epe(got.cpu(), ref).mean().item() < EPE_TOL
+    centre, _ = net(x[:, 3:6].cuda(), {})
+    assert torch.equal(centre, got)
+
+
 def test_uint8_frames_equal_float_frames(gpu):
     """Handing the engine u8 HWC frames (device-side /255) gives the same field as the reference's
     host-side float conversion (processing/videoflow_processor.py:152-157)."""

@@ -1,0 +1,128 @@
+"""MemFlow pair path (BASELINE config C4) against its CPU oracle, and the new
+entry points it needs (row softmax into split rows, transposed split planes, residual-add epilogue)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EPE_TOL = 1e-3
+
+
+def _pair(seed=0, **over):
+    from oracle import memflow_oracle as mm
+    from vfml.memflow_net import build_memflow_network, memflow_cfg, seeded_memflow_state_dict
+    cfg, ocfg = memflow_cfg(), mm.get_cfg()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+        setattr(ocfg, k, v)
+    sd = seeded_memflow_state_dict(cfg, seed)
+    net = build_memflow_network(cfg)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    ora = mm.build_network(ocfg)
+    ora.load_state_dict(sd)
+    ora.eval()
+    return net, ora
+
+
+@pytest.mark.parametrize("precision", ["f16x3"])
+def test_memflow_forward_matches_oracle(gpu, precision):
+    net, ora = _pair(precision=precision)
+    x = torch.rand(1, 2, 3, 128, 192, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    low_ref, ref = ora(x)
+    low, got = net(x.cuda())
+    assert got.shape == ref.shape == (1, 2, 128, 192) and low.shape == low_ref.shape
+    epe = (got.cpu() - ref).pow(2).sum(1).sqrt()
+    print(f"[memflow {precision}] mean EPE {epe.mean().item():.3e} px, max {epe.max().item():.3e}, |flow| {ref.abs().mean().item():.2f}")
+    assert epe.mean().item() < EPE_TOL
+    assert (low.cpu() - low_ref).abs().max().item() < 1e-3
+
+
+def test_readout_changes_the_flow(gpu):
+    """gamma = 0 switches the memory read-out off: the result must differ from gamma = 0.5 (the read-out
+    path is live) and still match its own oracle."""
+    net, ora = _pair()
+    x = torch.rand(1, 2, 3, 128, 128, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    _, a = net(x.cuda())
+    a = a.clone()
+    with torch.no_grad():
+        net.update_block.gamma.zero_()
+        ora.update_block.gamma.zero_()
+    _, b = net(x.cuda())
+    assert (a - b).abs().max().item() > 1e-3
+    assert (b.cpu() - ora(x)[1]).pow(2).sum(1).sqrt().mean().item() < EPE_TOL
+
+
+def test_softmax_rows_and_transposed_planes(gpu):
+    from tests_support import s16_decode
+    from vfml import hip
+    g = torch.Generator().manual_seed(5)
+    rows, cols, ld = 37, 203, 224
+    x = torch.randn(rows, ld, generator=g) * 4
+    out = torch.full((rows * 208,), 9.0, device=gpu)
+    hip.softmax_rows_s16(x.cuda().reshape(-1), rows, cols, ld, out, 208)
+    got = s16_decode(out, rows, 208, 208)
+    ref = torch.softmax(x[:, :cols].double(), dim=-1).float()
+    assert (got[:, cols:] == 0).all()
+    assert (got[:, :cols] - ref).abs().max().item() < 5e-7   # 22-bit split rows
+    v = torch.randn(50, 24, generator=g)
+    sw = hip.SplitWeight(24, 50, gpu).fill_transposed(v.cuda().reshape(-1), 50, ld=24, scale=4.0)
+    rec = (sw.hi.view(24, sw.kp).float() + sw.lo.view(24, sw.kp).float()).cpu() / 4.0
+    assert (rec[:, 50:] == 0).all()
+    assert ((rec[:, :50] - v.t()).abs() <= 2.0 ** -20 * v.t().abs() + 2.0 ** -22).all()
+
+
+def test_add_aux_epilogue_is_attention_readout(gpu):
+    """out = m + gamma * (A @ V) with A in split rows and V as transposed planes: the per-iteration GEMM."""
+    from tests_support import s16_decode
+    from vfml import hip
+    g = torch.Generator().manual_seed(6)
+    P, d = 264, 128
+    A = torch.softmax(torch.randn(P, P, generator=g), dim=-1)
+    V = torch.randn(P, d, generator=g)
+    m = torch.randn(P, d, generator=g)
+    ld = 288
+    A16 = torch.zeros(P * ld, device=gpu)
+    Apad = torch.zeros(P, ld)
+    Apad[:, :P] = A
+    hip.to_s16(Apad.cuda().reshape(-1), P, ld, ld, A16, ld)
+    m16 = torch.empty(P * d, device=gpu)
+    hip.to_s16(m.cuda().reshape(-1), P, d, d, m16, d)
+    vt = hip.SplitWeight(d, P, gpu).fill_transposed(V.cuda().reshape(-1), P, ld=d, scale=16.0)
+    out = torch.empty(P * d, device=gpu)
+    hip.conv2d(A16, P, ld, 1, 1, P, vt, None, d, 1, 1, out, d, out_scale=0.5, epilogue=hip.EPI_ADD_AUX,
+               aux0=m16, ld_aux0=d, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, aux_fmt=hip.FMT_S16)
+    got = s16_decode(out, P, d, d)
+    ref = (m.double() + 0.5 * (A.double() @ V.double())).float()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 5e-6
+
+
+def test_memflow_host_path_matches_oracle(gpu, tmp_path, monkeypatch):
+    """MemFlowInference.compute_optical_flow (window ending at the frame, 0..255 floats, range heuristic,
+    pad to /8, LAST TWO frames, unpad, CPU numpy) vs the oracle's restatement of the same script."""
+    import contextlib
+    import io
+    import os
+    import numpy as np
+    from oracle import memflow_oracle as mm
+    from processing.memflow_inference import MemFlowInference
+    from vfml.memflow_net import memflow_cfg, seeded_memflow_state_dict
+    from vfml.synth import synthetic_clip
+    os.makedirs(tmp_path / "MemFlow_ckpt")
+    sd = seeded_memflow_state_dict(memflow_cfg(), 0)
+    torch.save(sd, tmp_path / "MemFlow_ckpt" / "MemFlowNet_sintel.pth")
+    monkeypatch.chdir(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = MemFlowInference("cuda", sequence_length=3)
+        eng.load_model()
+    frames = synthetic_clip(4, 132, 200)                      # not multiples of 8: the padder is live
+    got = eng.compute_optical_flow(frames, 2)
+    assert got.shape == (132, 200, 2) and got.dtype == np.float32
+    ora = mm.build_network(mm.get_cfg()).eval()
+    ora.load_state_dict(sd)
+    x = torch.from_numpy(np.stack(frames[0:3])).permute(0, 3, 1, 2).float()[None]
+    ref = mm.compute_flow(ora, x).permute(1, 2, 0).numpy()
+    epe = np.sqrt(((got - ref) ** 2).sum(-1))
+    assert epe.mean() < EPE_TOL, epe.mean()
+    assert np.array_equal(eng.compute_optical_flow_tiled(frames, 2), got)      # MemFlow never tiles

@@ -281,3 +281,54 @@ def test_cli_fills_cache_with_injected_cpu_model(tmp_path, monkeypatch):
     with contextlib.redirect_stdout(out):
         assert flow_processor.main(argv) == 0
     assert "nothing to compute" in out.getvalue()
+
+
+def test_memflow_windows_and_errors_match_reference(tmp_path, monkeypatch):
+    """MemFlow half of the processing package vs the reference's own modules (fixtures)."""
+    from processing.memflow_core import MemFlowCore
+    from processing.memflow_inference import MemFlowInference
+    from processing.memflow_processor import MemFlowProcessor
+    for w in J["memflow_windows"]:
+        with quiet():
+            p = MemFlowProcessor("cpu", sequence_length=w["T"])
+        frames = [np.full((64, 64, 3), i, np.uint8) for i in range(6)]
+        t = p.prepare_frame_sequence(frames, w["i"])
+        assert t[0, :, 0, 0, 0].long().tolist() == w["idx"] and list(t.shape) == w["shape"]
+        assert str(t.dtype) == w["dtype"] and str(t.device) == w["device"] and len(frames) == 6
+    assert list(p.calculate_tile_grid(1920, 1080)) == J["memflow_tile_grid"]
+    assert p.extract_tile(frames[0], {}) is frames[0]
+    E = J["memflow_errors"]
+    kinds = {"ValueError": ValueError, "TypeError": TypeError, "RuntimeError": RuntimeError,
+             "FileNotFoundError": FileNotFoundError}
+    monkeypatch.chdir(tmp_path)
+    with quiet():
+        mc = MemFlowCore("cpu")
+    args = {"type": np.zeros((1, 2, 3, 64, 64)), "ndim": torch.zeros(2, 3, 64, 64), "batch": torch.zeros(2, 2, 3, 64, 64),
+            "frames": torch.zeros(1, 1, 3, 64, 64), "channels": torch.zeros(1, 2, 4, 64, 64),
+            "small": torch.zeros(1, 2, 3, 32, 64)}
+    for key, arg in args.items():
+        with pytest.raises(kinds[E[key][0]]) as e:
+            mc.validate_input_tensor(arg)
+        assert str(e.value) == E[key][1]
+    with pytest.raises(RuntimeError) as e:
+        mc.compute_flow_from_tensor(torch.zeros(1, 2, 3, 64, 64))
+    assert str(e.value) == E["not_loaded"][1]
+    with pytest.raises(FileNotFoundError) as e:
+        mc.load_model()
+    assert str(e.value) == E["missing"][1]
+    seqs = {"empty": [], "one": [np.zeros((64, 64, 3), np.uint8)], "small": [np.zeros((32, 64, 3), np.uint8)] * 2,
+            "mismatch": [np.zeros((64, 64, 3), np.uint8), np.zeros((64, 72, 3), np.uint8)]}
+    for key, fr in seqs.items():
+        with pytest.raises(ValueError) as e:
+            p.validate_frame_sequence(fr)
+        assert str(e.value) == E["seq_" + key][1]
+    with quiet():
+        inf = MemFlowInference("cpu", sequence_length=3)
+    assert inf.model is None and inf.get_processor().sequence_length == 3
+    assert inf.calculate_tile_grid(64, 64)[2:4] == (1, 1)
+    assert inf.get_memory_usage() == {'device': 'cpu', 'note': 'CPU memory tracking not available'}
+    # the value-range heuristic of the reference's inference script (memflow_inference_isolated.py:81-85)
+    x = torch.tensor([0.0, 127.5, 255.0])
+    assert torch.equal(MemFlowCore.normalise(x), torch.tensor([-1.0, 0.0, 1.0]))
+    assert torch.equal(MemFlowCore.normalise(x / 255.0 * 1.5), 2 * (x / 255.0 * 1.5) - 1)
+    assert torch.equal(MemFlowCore.normalise(x / 255.0), x / 255.0)

@@ -35,6 +35,9 @@ class VideoFlowCore:
         cfg.model = model_path
         if self.fast_mode:  # reference :91-94
             cfg.decoder_depth, cfg.corr_levels, cfg.corr_radius = 6, 3, 3
+        # The reference passes the same cfg whatever the architecture (its comment at :100 expects the
+        # network to be "detected from the weights"); here 'bof' selects the tri-frame network explicitly.
+        cfg.network = "BOFNet" if self.architecture == "bof" else "MOFNetStack"
         if not os.path.exists(model_path):
             raise FileNotFoundError(f"VideoFlow model weights not found: {model_path}")
         self.cfg = cfg

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
             const float h = a.aux1[(int64_t)row * a.ld_aux1 + col];
             v = (1.f - z) * h + z * tanhf(v);
           } break;
+          case VFML_EPI_ADD_AUX: v += a.aux0[(int64_t)row * a.ld_aux0 + col]; break;
           default: break;
         }
         a.out[(int64_t)row * a.ldo + col] = v;
@@ -258,7 +259,7 @@ extern "C" int vfml_conv2d(const vfml_conv_desc* d, void* stream) {
   if (d->epilogue == VFML_EPI_GRU_ZR)
     VFML_REQUIRE(d->aux0 && d->split > 0 && d->split < d->cout, "vfml_conv2d: GRU_ZR needs aux0 and split");
   if (d->epilogue == VFML_EPI_GRU_Q) VFML_REQUIRE(d->aux0 && d->aux1, "vfml_conv2d: GRU_Q needs aux0 and aux1");
-  VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_GRU_Q, "vfml_conv2d: bad epilogue");
+  VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_ADD_AUX, "vfml_conv2d: bad epilogue");
 
   ConvArgs a;
   a.in0 = d->in0; a.in1 = two ? d->in1 : d->in0;

@@ -97,6 +97,7 @@ __device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float
     case VFML_EPI_TANH_RELU: return lowhalf ? tanhf(v) : fmaxf(v, 0.f);
     case VFML_EPI_GRU_ZR: v = sigmoidf_(v); return lowhalf ? v : v * x0;
     case VFML_EPI_GRU_Q: return (1.f - x0) * x1 + x0 * tanhf(v);
+    case VFML_EPI_ADD_AUX: return x0 + v;
     default: return v;
   }
 }
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void conv_gemm_split_ker
           x0 = aux4(a.aux0, a.ld_aux0, grow, col);
           x1 = aux4(a.aux1, a.ld_aux1, grow, col);
         }
+        if (epi == VFML_EPI_ADD_AUX) x0 = aux4(a.aux0, a.ld_aux0, grow, col);
       } else {
         for (int e = 0; e < nvalid; ++e) {   // ragged tail: f32 operands only (host check)
           if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e - a.split];
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void conv_gemm_split_ker
             x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
             x1[e] = a.aux1[(int64_t)grow * a.ld_aux1 + col + e];
           }
+          if (epi == VFML_EPI_ADD_AUX) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
         }
       }
 #pragma unroll
@@ -503,7 +506,86 @@ __global__ void to_s16_kernel(const float* __restrict__ src, int64_t rows, int c
   }
 }
 
+// [rows][c] f32 -> planes [c][kp] of the transpose: 64x64 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ src, int rows, int c, int ld,
+                                                              int kp, float scale, _Float16* __restrict__ hi,
+                                                              _Float16* __restrict__ lo) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rr = i >> 6, cc = i & 63;
+    const int r = r0 + rr, col = c0 + cc;
+    tile[rr][cc] = (r < rows && col < c) ? src[(int64_t)r * ld + col] * scale : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int cc = i >> 5, kk = (i & 31) * 2;
+    const int col = c0 + cc, k = r0 + kk;
+    if (col >= c || k >= kp) continue;
+    const float a = tile[kk][cc], b = tile[kk + 1][cc];
+    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    *reinterpret_cast<fp16x2*>(hi + (int64_t)col * kp + k) = h;
+    *reinterpret_cast<fp16x2*>(lo + (int64_t)col * kp + k) = l;
+  }
+}
+
+// one workgroup per row; three sweeps (max, sum of exp, write) over a row that stays in L2
+__global__ __launch_bounds__(256) void softmax_rows_s16_kernel(const float* __restrict__ x, int cols, int64_t ld_in,
+                                                               float* __restrict__ out, int64_t ld_out) {
+  __shared__ float red[4];
+  const float* row = x + (int64_t)blockIdx.x * ld_in;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  float m = -INFINITY;
+  for (int c = t; c < cols; c += 256) m = fmaxf(m, row[c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = t; c < cols; c += 256) s += expf(row[c] - m);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / s;
+  float* orow = out + (int64_t)blockIdx.x * ld_out;
+  const int nq = (int)(ld_out / 4);
+  for (int q4 = t; q4 < nq; q4 += 256) {
+    const int c = q4 * 4;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = c + e < cols ? expf(row[c + e] - m) * inv : 0.f;
+    U8 hh, ll;
+    split4(v, hh, ll, 0);
+    char* u = reinterpret_cast<char*>(orow + (c & ~7)) + (c & 4) * 2;
+    *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hh.v, hh.v, 0, 1, 2, 3));
+    *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(ll.v, ll.v, 0, 1, 2, 3));
+  }
+}
+
 }  // namespace
+
+extern "C" int vfml_transpose_split_f16(const float* src, int rows, int c, int ld, float scale, void* hi, void* lo,
+                                        int kp, void* stream) {
+  VFML_REQUIRE(src && hi && lo && rows > 0 && c > 0 && ld >= c, "vfml_transpose_split_f16: bad argument");
+  VFML_REQUIRE(kp >= rows && kp % 32 == 0 && scale > 0.f, "vfml_transpose_split_f16: kp must be rows rounded up to 32");
+  VFML_REQUIRE(vfml_aligned16(hi) && vfml_aligned16(lo), "vfml_transpose_split_f16: alignment");
+  hipLaunchKernelGGL(transpose_split_kernel, dim3((kp + 63) / 64, (c + 63) / 64), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, rows, c, ld, kp, scale, (_Float16*)hi, (_Float16*)lo);
+  return vfml_check_launch("vfml_transpose_split_f16");
+}
+
+extern "C" int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out,
+                                     void* stream) {
+  VFML_REQUIRE(x && out && rows > 0 && rows < (1ll << 31) && cols > 0 && ld_in >= cols && ld_out >= cols && ld_out % 8 == 0,
+               "vfml_softmax_rows_s16: bad shape (ld_out %% 8 == 0, ld_out >= cols)");
+  VFML_REQUIRE((reinterpret_cast<uintptr_t>(out) & 31u) == 0, "vfml_softmax_rows_s16: out must be 32-byte aligned");
+  hipLaunchKernelGGL(softmax_rows_s16_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     cols, ld_in, out, ld_out);
+  return vfml_check_launch("vfml_softmax_rows_s16");
+}
 
 extern "C" int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream) {
   VFML_REQUIRE(src && dst && rows > 0 && c > 0 && c % 4 == 0 && ld_src >= c && ld_src % 4 == 0 && ld_dst % 8 == 0 &&
@@ -577,9 +659,10 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   if (d->epilogue == VFML_EPI_GRU_ZR || d->epilogue == VFML_EPI_TANH_RELU)
     VFML_REQUIRE(d->split > 0 && d->split < d->cout && d->split % 4 == 0,
                  "vfml_conv2d_split: split=%d must be a multiple of 4 inside (0, cout)", d->split);
-  if (d->epilogue == VFML_EPI_GRU_ZR) VFML_REQUIRE(d->aux0, "vfml_conv2d_split: GRU_ZR needs aux0");
+  if (d->epilogue == VFML_EPI_GRU_ZR || d->epilogue == VFML_EPI_ADD_AUX)
+    VFML_REQUIRE(d->aux0, "vfml_conv2d_split: this epilogue needs aux0");
   if (d->epilogue == VFML_EPI_GRU_Q) VFML_REQUIRE(d->aux0 && d->aux1, "vfml_conv2d_split: GRU_Q needs aux0 and aux1");
-  VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_GRU_Q, "vfml_conv2d_split: bad epilogue");
+  VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_ADD_AUX, "vfml_conv2d_split: bad epilogue");
 
   SplitArgs a;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)

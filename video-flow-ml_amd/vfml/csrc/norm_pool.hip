@@ -88,22 +88,35 @@ __global__ __launch_bounds__(STAT_THREADS) void instnorm_partial_kernel(const fl
   }
 }
 
-__global__ void instnorm_final_kernel(const double* __restrict__ part, int n, int chunks, int c, int hw, float eps,
-                                      float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * c) return;
+// One wave per (n, channel): lanes stride over the chunk partials, then lane 0 folds the 64 lane sums
+// in lane order (fixed association -> bitwise reproducible).
+__global__ __launch_bounds__(64) void instnorm_final_kernel(const double* __restrict__ part, int n, int chunks, int c,
+                                                           int hw, float eps, float* __restrict__ stats) {
+  __shared__ double sh[64][2];
+  const int i = blockIdx.x;   // n * c blocks
   const int nn = i / c, ch = i - nn * c;
+  const int lane = threadIdx.x;
   double s = 0, q = 0;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const double* p = part + (((int64_t)nn * chunks + k) * c + ch) * 2;
     s += p[0];
     q += p[1];
   }
-  const double mean = s / hw;
-  double var = q / hw - mean * mean;
-  if (var < 0) var = 0;
-  stats[2 * i + 0] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  sh[lane][0] = s;
+  sh[lane][1] = q;
+  __syncthreads();
+  if (lane == 0) {
+    double ss = 0, qq = 0;
+    for (int l = 0; l < 64; ++l) {
+      ss += sh[l][0];
+      qq += sh[l][1];
+    }
+    const double mean = ss / hw;
+    double var = qq / hw - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i + 0] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // ------------------------------------------------------------------ instance-norm apply
@@ -204,8 +217,8 @@ extern "C" int vfml_instnorm_stats(const float* x, int n, int hw, int c, float e
                      (double*)workspace);
   int rc = vfml_check_launch("vfml_instnorm_stats(partial)");
   if (rc) return rc;
-  hipLaunchKernelGGL(instnorm_final_kernel, dim3((n * c + 127) / 128), dim3(128), 0, s, (const double*)workspace, n,
-                     chunks, c, hw, eps, stats);
+  hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(64), 0, s, (const double*)workspace, n, chunks, c, hw,
+                     eps, stats);
   return vfml_check_launch("vfml_instnorm_stats(final)");
 }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvfml_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip"]
 
-EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q = range(7)
+EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 
 
@@ -70,6 +70,8 @@ def lib():
     L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
     L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
     L.vfml_to_s16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]
+    L.vfml_softmax_rows_s16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_void_p]
+    L.vfml_transpose_split_f16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_frames_to_nhwc4.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
     L.vfml_instnorm_workspace_bytes.restype = c_int64
@@ -85,14 +87,15 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 4:
+    if L.vfml_abi_version() != 5:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
 
 
 EXPORTS = [
-    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
+    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
+    "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
     "vfml_convex_upsample", "vfml_last_error", "vfml_abi_version",
 ]
@@ -146,13 +149,14 @@ def profile_end():
     return out
 
 
-def conv_variant(cout, split=False):
-    """Which template instantiation vfml_conv2d[_split] dispatches to (conv_gemm[_split].hip)."""
-    # (bench.py's roofline leg groups launches by family; the split kernel picks 64- or 128-wide tiles
-    # per shape, which is a tuning detail inside one kernel family)
-    if split:
-        return "conv_gemm_split_kernel"
-    return "conv_gemm_kernel" + ("<128,2,2>" if cout > 64 else ("<64,2,2>" if cout > 32 else "<32,4,1>"))
+def conv_variant(cout, split=False, ctot=32, in16=False):
+    """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (the
+    split kernel's rare 64-wide choice for cout > 64 is not modelled here)."""
+    tile = "128, 2, 2" if cout > 64 else ("64, 2, 2" if cout > 32 else "32, 4, 1")
+    if not split:
+        return f"conv_gemm_kernel<{tile}>"
+    bigc = "true" if (ctot >= 32 or in16) else "false"
+    return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
 
 
 class SplitWeight:
@@ -172,6 +176,14 @@ class SplitWeight:
         if not (absmax > 0.0) or not math.isfinite(absmax):
             return 1.0
         return 2.0 ** math.floor(math.log2(16384.0 / absmax))
+
+    def fill_transposed(self, src, rows_src, ld=None, scale=1.0, src_off=0):
+        """src: flat f32 [rows_src][self.rows] (row stride ld): planes of its transpose, k = source row."""
+        self.scale = float(scale)
+        _check(lib().vfml_transpose_split_f16(_ptr(_dev(src), src_off), rows_src, self.rows, ld or self.rows,
+                                              self.scale, c_void_p(self.hi.data_ptr()), c_void_p(self.lo.data_ptr()),
+                                              self.kp, _stream()), "vfml_transpose_split_f16")
+        return self
 
     def fill(self, src, src_off=0, ld=None, scale=1.0):
         """src: flat f32 device tensor holding [rows][k] at float offset src_off with row stride ld."""
@@ -222,7 +234,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     e0.record()
     launch()
     e1.record()
-    _PROFILE.append((conv_variant(cout, is_split), 2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
+    _PROFILE.append((conv_variant(cout, is_split, c0 + c1, in_fmt == FMT_S16), 2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):
@@ -255,6 +267,12 @@ def instnorm_apply(x, stats, n, hw, c, out, res=None, res_stats=None):
 
 def avgpool2x2(x, n, h, w, c, out):
     _check(lib().vfml_avgpool2x2(_ptr(_dev(x)), n, h, w, c, _ptr(_dev(out)), _stream()), "vfml_avgpool2x2")
+
+
+def softmax_rows_s16(x, rows, cols, ld_in, out, ld_out, x_off=0, out_off=0):
+    """Row softmax of f32 scores -> split rows (FMT_S16), zero-filled to ld_out."""
+    _check(lib().vfml_softmax_rows_s16(_ptr(_dev(x), x_off), rows, cols, ld_in, _ptr(_dev(out), out_off), ld_out,
+                                       _stream()), "vfml_softmax_rows_s16")
 
 
 def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):

@@ -1,0 +1,279 @@
+"""MemFlowNetHIP — the MemFlow pair network on the vfml HIP kernels.
+
+Stands in for what reference processing/memflow_inference_isolated.py:54-107 builds out of the
+(absent) MemFlow submodule: `build_network(cfg)` + `InferenceCore(model).step(pair, end=True)` on the
+last two frames of the window, with an empty memory bank.  Architecture: DESIGN.md §2b / oracle/
+memflow_oracle.py — RAFT encoders and one correlation pyramid (previous -> current frame), an update
+block whose motion features get a memory read-out added,  m_global = m + gamma * softmax(q k^T/sqrt(d)) v,
+where (with the empty bank) keys and values are the frame's own.
+
+MI355X shape of the read-out: q and k come from the context features and do not change over the
+iterations, so the P x P attention matrix is computed ONCE per field, kept resident in HBM as
+split-row halves (4.2 GB at 1080p; no flash-style re-computation needed with 288 GB), and every
+iteration is one long-K GEMM  attn[P,P] . v[P,128]  on the MFMA kernel with the residual add fused.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .network import MOFNetHIP, _Holder
+from .weights import pack_conv_weight
+
+
+def memflow_conv_spec(cfg):
+    from .weights import _encoder_spec
+    cor = cfg.corr_levels * (2 * cfg.corr_radius + 1) ** 2
+    hid, ad = cfg.feat_dim // 2, cfg.att_dim
+    ub = "update_block"
+    s = _encoder_spec("fnet", cfg.feat_dim) + _encoder_spec("cnet", cfg.feat_dim)
+    s += [("query", ad, hid, 1, 1), ("key", ad, hid, 1, 1),
+          (f"{ub}.encoder.convc1", 256, cor, 1, 1), (f"{ub}.encoder.convc2", 192, 256, 3, 3),
+          (f"{ub}.encoder.convf1", 128, 2, 7, 7), (f"{ub}.encoder.convf2", 64, 128, 3, 3),
+          (f"{ub}.encoder.conv", 128 - 4, 192 + 64, 3, 3), (f"{ub}.value", ad, 128, 1, 1)]
+    for nm, kh, kw in (("z1", 1, 5), ("r1", 1, 5), ("q1", 1, 5), ("z2", 5, 1), ("r2", 5, 1), ("q2", 5, 1)):
+        s.append((f"{ub}.gru.conv{nm}", hid, hid + 3 * 128, kh, kw))
+    s += [(f"{ub}.flow_head.conv1", 256, hid, 3, 3), (f"{ub}.flow_head.conv2", 2, 256, 3, 3),
+          (f"{ub}.mask.0", 256, hid, 3, 3), (f"{ub}.mask.2", 64 * 9, 256, 1, 1)]
+    return s
+
+
+def memflow_cfg():
+    from .cfg import Cfg
+    return Cfg(restore_ckpt="", network="MemFlowNet", feat_dim=256, down_ratio=8, corr_levels=4, corr_radius=4,
+               decoder_depth=12, att_dim=128, precision="f16x3",
+               input_scale=1.0, input_shift=0.0)   # frames reach the network already in [-1, 1]
+
+
+def seeded_memflow_state_dict(cfg, seed=0, gamma=0.5):
+    import math
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, cout, cin, kh, kw in memflow_conv_spec(cfg):
+        bound = 1.0 / math.sqrt(cin * kh * kw)
+        sd[f"{name}.weight"] = (torch.rand(cout, cin, kh, kw, generator=g) * 2 - 1) * bound
+        sd[f"{name}.bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
+    sd["update_block.gamma"] = torch.tensor([gamma])      # upstream initialises 0; non-zero exercises the read-out
+    return sd
+
+
+class MemFlowNetHIP(MOFNetHIP):
+    def __init__(self, cfg):
+        _Holder.__init__(self)
+        import collections
+        self.cfg = cfg
+        self.hidden_dim = self.context_dim = cfg.feat_dim // 2
+        self.tri_frame = False
+        self._spec = memflow_conv_spec(cfg)
+        for name, cout, cin, kh, kw in self._spec:
+            leaf = self
+            for p in name.split("."):
+                leaf = leaf.child(p)
+            leaf.weight = nn.Parameter(torch.zeros(cout, cin, kh, kw), requires_grad=False)
+            leaf.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        self.child("update_block").gamma = nn.Parameter(torch.zeros(1), requires_grad=False)
+        self._packed = None
+        self._packed_key = None
+        self._packed_serial = 0
+        self._ws = {}
+        self._feat_cache = collections.OrderedDict()
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, device):
+        split = self._precision() == "f16x3"
+        key = (str(device), split, tuple(p._version for p in self.parameters()),
+               tuple(p.data_ptr() for p in self.parameters()))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        P, hid = {}, self.hidden_dim
+        ub = "update_block"
+        for name, cout, cin, kh, kw in self._spec:
+            leaf = self._param(name)
+            w = leaf.weight.detach().to(device=device, dtype=torch.float32)
+            b = leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+            if name.endswith(".encoder.convc1"):       # lookup block padded to whole units (zero weights)
+                cor_p = (cin + 7) // 8 * 8 if split else (cin + 3) // 4 * 4
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cor_p - cin))
+            P[name] = (pack_conv_weight(w, cin_pad=4 if cin in (2, 3) else None), b)
+        self._cout_of = {}
+        for k in ("1", "2"):
+            raw = {g: self._param(f"{ub}.gru.conv{g}{k}") for g in "zrq"}
+            wzr = torch.cat([raw["z"].weight, raw["r"].weight]).detach().to(device=device, dtype=torch.float32)
+            bzr = torch.cat([raw["z"].bias, raw["r"].bias]).detach().to(device=device, dtype=torch.float32)
+            wq = raw["q"].weight.detach().to(device=device, dtype=torch.float32)
+            bq = raw["q"].bias.detach().to(device=device, dtype=torch.float32)
+            for nm, wfull, bfull, co in ((f"{ub}.gru.convzr{k}", wzr, bzr, 2 * hid), (f"{ub}.gru.convq{k}", wq, bq, hid)):
+                it = torch.cat([wfull[:, :hid], wfull[:, 2 * hid:]], dim=1)
+                P[nm + ".iter"] = (pack_conv_weight(it), None)
+                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid]), bfull.contiguous())
+                self._cout_of[nm + ".iter"] = co
+            for g in "zrq":
+                del P[f"{ub}.gru.conv{g}{k}"]
+        if split:
+            with torch.cuda.device(device):
+                for name, (wflat, b) in list(P.items()):
+                    cout = self._cout_of[name] if name in self._cout_of else b.numel()
+                    sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
+                    P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
+        self._packed, self._packed_key = P, key
+        self._packed_serial += 1
+        self._feat_cache.clear()
+        return P
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, pair, data=None):
+        """pair: float [1, 2, 3, H, W] in [-1, 1] on the GPU (previous, current).
+        Returns (flow_low [1,2,h,w], flow [1,2,H,W]) like InferenceCore.step(..., end=True)."""
+        if not isinstance(pair, torch.Tensor) or not pair.is_cuda:
+            raise RuntimeError("MemFlowNetHIP runs on an MI355X (HIP) device only; got "
+                               f"{getattr(pair, 'device', type(pair))}. There is no CPU fallback in the shipped engine.")
+        if pair.dim() != 5 or pair.shape[0] != 1 or pair.shape[1] != 2 or pair.shape[2] != 3:
+            raise ValueError(f"pair must be [1,2,3,H,W], got {tuple(pair.shape)}")
+        cfg = self.cfg
+        src = pair[0].float().contiguous()
+        H, W = src.shape[2], src.shape[3]
+        if H % 8 or W % 8:
+            raise ValueError("H and W must be multiples of 8 (use InputPadder)")
+        L, R, D, AD = cfg.corr_levels, cfg.corr_radius, cfg.feat_dim, cfg.att_dim
+        h, w = H // 8, W // 8
+        if (h >> (L - 1)) < 2 or (w >> (L - 1)) < 2:
+            raise ValueError(f"frame {H}x{W} too small for a {L}-level correlation pyramid")
+        dev = src.device
+        Pn = h * w
+        P = self._pack(dev)
+        if self._precision() != "f16x3":
+            raise ValueError("the MemFlow path is built on the split-f16 kernels: cfg.precision must be 'f16x3'")
+        split, AF = True, hip.FMT_S16
+        cor = L * (2 * R + 1) ** 2
+        cor_p = (cor + 7) // 8 * 8 if split else (cor + 3) // 4 * 4
+        ub = "update_block"
+        gamma = float(self._param(ub).gamma.item())
+
+        with torch.cuda.device(dev):
+            hl, wl = [h], [w]
+            for l in range(1, L):
+                hl.append(hl[-1] // 2)
+                wl.append(wl[-1] // 2)
+            Sl = [hl[l] * wl[l] for l in range(L)]
+            ldl = [(s + 31) // 32 * 32 for s in Sl]
+            feats = self._frame_features(src, [0, 1], None, H, W, P, dev, L, hl, wl, Sl)
+            ctx = self._frame_context_plain(src, H, W, P, dev, Pn, AF)
+            pyr = [self._buf(f"mpyr_{l}", Pn * ldl[l], dev) for l in range(L)]
+            for l in range(L):
+                hip.conv2d(feats[0][0], D, D, 1, 1, Pn, feats[1][1][l], None, Sl[l], 1, 1, pyr[l], ldl[l],
+                           out_scale=1.0 / float(D) ** 0.5, in_fmt=AF)
+
+            GLD, Z, RH, HH, INP, MF, MT = 768, 0, 128, 256, 384, 512, 640
+            G = self._buf("gru_state", Pn * GLD, dev)
+            G.view(Pn, GLD)[:, HH:HH + 256].copy_(ctx.view(Pn, 256))
+            # context parts of the GRU gates (+ bias), once per field
+            gate_add = {}
+            for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+                for g, co in (("zr", 256), ("q", 128)):
+                    wgt, b = P[f"{ub}.gru.conv{g}{k}.ctx"]
+                    a = self._buf(f"gate_add_{g}{k}", Pn * co, dev)
+                    hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, co, kh, kw, a, co, in0_off=INP, pad_h=kh // 2,
+                               pad_w=kw // 2, in_fmt=AF)
+                    gate_add[g + k] = a
+
+            # memory read-out operator: attn = softmax(q k^T / sqrt(d)), P x P, once per field
+            P8 = (Pn + 7) // 8 * 8
+            ldA = (P8 + 31) // 32 * 32
+            qmap = self._buf("att_q", Pn * AD, dev)
+            kmap = self._buf("att_k", Pn * AD, dev)
+            wgt, b = P["query"]
+            hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, qmap, AD, in0_off=INP, in_fmt=AF, out_fmt=AF)
+            wgt, b = P["key"]
+            hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, kmap, AD, in0_off=INP, in_fmt=AF)
+            kw_ = hip.SplitWeight(Pn, AD, dev).fill(kmap, scale=16.0)
+            scores = self._buf("att_scores", Pn * ldA, dev)
+            hip.conv2d(qmap, AD, AD, 1, 1, Pn, kw_, None, Pn, 1, 1, scores, ldA, out_scale=1.0 / float(AD) ** 0.5,
+                       in_fmt=AF)
+            attn = self._buf("att_probs", Pn * ldA, dev)
+            hip.softmax_rows_s16(scores, Pn, Pn, ldA, attn, ldA)
+
+            corr = self._buf("mcorr", Pn * cor_p, dev, zero=True)
+            c1 = self._buf("c1", Pn * 256, dev)
+            cf = self._buf("cf", Pn * 256, dev)
+            f1 = self._buf("f1", Pn * 128, dev)
+            fh = self._buf("fh", Pn * 256, dev)
+            val = self._buf("att_v", Pn * AD, dev)
+            flow4 = self._buf("flow4", Pn * 4, dev)
+            delta = self._buf("mdelta", Pn * 4, dev, zero=True)     # channels 2,3 stay zero: no backward flow here
+            coords1 = self._buf("coords1", Pn * 4, dev)
+            vt = hip.SplitWeight(AD, P8, dev)
+            rows_per_call = max(128, ((1 << 30) // (ldA * 4) - 2) // 128 * 128)   # each A window < 1 GiB
+
+            hip.coords_init(coords1, 1, h, w)
+            hip.coords_update(coords1, None, 1, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
+                              fmt_b=AF)
+            for it in range(cfg.decoder_depth):
+                hip.corr_lookup(pyr, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, cor_p, out_fmt=AF)
+                wgt, b = P[f"{ub}.encoder.convc1"]
+                hip.conv2d(corr, cor_p, cor_p, 1, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
+                           in_fmt=AF, out_fmt=AF)
+                wgt, b = P[f"{ub}.encoder.convc2"]
+                hip.conv2d(c1, 256, 256, 1, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+                           in_fmt=AF, out_fmt=AF)
+                wgt, b = P[f"{ub}.encoder.convf1"]
+                hip.conv2d(flow4, 4, 4, 1, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                           out_fmt=AF)
+                wgt, b = P[f"{ub}.encoder.convf2"]
+                hip.conv2d(f1, 128, 128, 1, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                # motion features [conv out (124) | fx, fy, 0, 0]: the flow quad is written by coords_update
+                wgt, b = P[f"{ub}.encoder.conv"]
+                hip.conv2d(cf, 256, 256, 1, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                # value map and memory read-out  m_global = m + gamma * attn . v
+                wgt, b = P[f"{ub}.value"]
+                hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, val, AD, in0_off=MF, in_fmt=AF)
+                vt.fill_transposed(val, Pn, ld=AD, scale=16.0)
+                for r0 in range(0, Pn, rows_per_call):      # rows as the batch axis: 1x1 "images"
+                    nr = min(rows_per_call, Pn - r0)
+                    hip.conv2d(attn, P8, ldA, nr, 1, 1, vt, None, AD, 1, 1, G, GLD, in0_off=r0 * ldA,
+                               out_off=r0 * GLD + MT, out_scale=gamma, epilogue=hip.EPI_ADD_AUX,
+                               aux0=G, ld_aux0=GLD, aux0_off=r0 * GLD + MF, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+                    wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
+                    hip.conv2d(G, 128, GLD, 1, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
+                               in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
+                               epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
+                               addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                    wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
+                    hip.conv2d(G, 128, GLD, 1, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
+                               in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
+                               epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
+                               aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
+                               in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                wgt, b = P[f"{ub}.flow_head.conv1"]
+                hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                wgt, b = P[f"{ub}.flow_head.conv2"]
+                hip.conv2d(fh, 256, 256, 1, h, w, wgt, b, 2, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
+                hip.coords_update(coords1, delta, 1, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                                  flow_b_off=MF + 124, fmt_b=AF)
+
+            mask = self._buf("mmask", Pn * 576, dev)
+            wgt, b = P[f"{ub}.mask.0"]
+            hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                       epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+            wgt, b = P[f"{ub}.mask.2"]
+            hip.conv2d(fh, 256, 256, 1, h, w, wgt, b, 576, 1, 1, mask, 576, out_scale=0.25, in_fmt=AF)
+            up = torch.empty(H, W, 2, device=dev, dtype=torch.float32)
+            hip.convex_upsample(coords1, 0, 0, mask, 0, 576, h, w, up.view(-1))
+            low = flow4.view(h, w, 4)[..., :2].permute(2, 0, 1).unsqueeze(0).clone()
+        return low, up.permute(2, 0, 1).unsqueeze(0)
+
+    def _frame_context_plain(self, src, H, W, P, dev, Pn, AF):
+        """cnet on the previous frame (index 0 of the pair): [Pn*256] = tanh | relu halves."""
+        frames = self._buf("frames", H * W * 4, dev)
+        hip.frames_to_nhwc4(src[0:1].contiguous(), 1, H, W, float(self.cfg.input_scale), float(self.cfg.input_shift),
+                            frames)
+        ctx = torch.empty(Pn * 256, device=dev)
+        self._encoder("cnet", frames, 1, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim, out_fmt=AF)
+        return ctx
+
+
+def build_memflow_network(cfg):
+    return MemFlowNetHIP(cfg)

@@ -45,6 +45,9 @@ class MOFNetHIP(_Holder):
         self.hidden_dim = self.context_dim = cfg.feat_dim // 2
         if cfg.feat_dim != 256:
             raise ValueError("MOFNetHIP is built for feat_dim=256")
+        # 'BOFNet': the tri-frame member of the family - the same blocks on the centre triple of the
+        # window (previous, current, next), output [B, 2, 2, H, W] = (forward, backward) of the centre frame
+        self.tri_frame = getattr(cfg, "network", "MOFNetStack") == "BOFNet"
         self._spec = conv_spec(cfg)
         for name, cout, cin, kh, kw in self._spec:
             leaf = self
@@ -325,6 +328,11 @@ class MOFNetHIP(_Holder):
         cfg = self.cfg
         if N < 3:
             raise ValueError(f"need at least 3 frames, got {N}")
+        if self.tri_frame and N > 3:
+            lo = N // 2 - 1
+            src = src[lo:lo + 3].contiguous()
+            frame_keys = frame_keys[lo:lo + 3] if frame_keys is not None else None
+            N = 3
         if H % 8 or W % 8:
             raise ValueError("H and W must be multiples of 8 (use InputPadder)")
         L, R, D = cfg.corr_levels, cfg.corr_radius, cfg.feat_dim
