@@ -114,3 +114,37 @@ def test_engine_refuses_cpu_tensors():
     net = build_network(get_cfg())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 3, 128, 128), {})
+
+
+@pytest.mark.parametrize("model", ["videoflow", "memflow"])
+def test_cli_on_gpu_writes_the_cache_the_api_would(gpu, tmp_path, monkeypatch, model):
+    """flow_processor.py end to end on the GPU (resident clip, sharded runner with world=1): every cached
+    field equals the field the reference API path computes for that frame."""
+    import contextlib
+    import io
+    import os
+    import numpy as np
+    import flow_processor
+    from processing.flow_inference import VideoFlowInference
+    from processing.memflow_inference import MemFlowInference
+    from vfml import get_cfg
+    from vfml.memflow_net import memflow_cfg, seeded_memflow_state_dict
+    from vfml.synth import synthetic_clip
+    from vfml.weights import write_seeded_checkpoint
+    write_seeded_checkpoint(str(tmp_path), get_cfg(), seed=0)
+    os.makedirs(tmp_path / "MemFlow_ckpt")
+    torch.save(seeded_memflow_state_dict(memflow_cfg(), 0), tmp_path / "MemFlow_ckpt" / "MemFlowNet_sintel.pth")
+    monkeypatch.chdir(tmp_path)
+    argv = ["--input", "synthetic:160x128x5", "--output", str(tmp_path / "out"), "--device", "cuda", "--model", model,
+            "--sequence-length", "3", "--interactive", "--skip-lods"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert flow_processor.main(argv) == 0
+        eng = (MemFlowInference("cuda", sequence_length=3) if model == "memflow"
+               else VideoFlowInference("cuda", sequence_length=3))
+        eng.load_model()
+    tag = "memflow_sintel" if model == "memflow" else "videoflow_mof_sintel_standard"
+    cache = tmp_path / "out" / f"synthetic_160x128x5_flow_cache_{tag}_seq3_start0_frames5"
+    frames = synthetic_clip(5, 128, 160)
+    for i in (0, 2, 4):
+        got = np.load(cache / f"flow_frame_{i:06d}.npz")["flow"]
+        assert np.array_equal(got, eng.compute_optical_flow(frames, i)), i

@@ -26,6 +26,7 @@ import torch
 
 from config import DeviceManager
 from processing.flow_inference import VideoFlowInference
+from processing.memflow_inference import MemFlowInference
 from storage import FlowCacheManager
 from vfml import dist as vdist
 from vfml.runner import run_sharded
@@ -104,8 +105,6 @@ def main(argv=None):
     rank, local_rank, world = vdist.init_distributed()
     log = print if rank == 0 else (lambda *a, **k: None)
 
-    if args.model != 'videoflow':
-        raise SystemExit("--model memflow is not built in this round (DESIGN.md, out of scope); use --model videoflow")
     for flag, on in (("--taa", args.taa), ("--show-tiles", args.show_tiles), ("--flow-input", args.flow_input)):
         if on:
             log(f"note: {flag} concerns video composition / visualisation, which this build does not do; ignored")
@@ -121,21 +120,26 @@ def main(argv=None):
     n = len(frames)
     mgr = FlowCacheManager()
     cache_src = args.input if not args.input.startswith('synthetic:') else os.path.join(args.output, args.input.replace(':', '_') + ".npy")
-    cache_dir = args.use_flow_cache or mgr.generate_cache_path(cache_src, start, n, args.sequence_length, args.fast,
-                                                               args.tile, 'videoflow', args.vf_dataset,
-                                                               args.vf_architecture, args.vf_variant)
+    memflow = args.model == 'memflow'
+    cache_dir = args.use_flow_cache or mgr.generate_cache_path(
+        cache_src, start, n, args.sequence_length, args.fast, args.tile, args.model,
+        args.stage if memflow else args.vf_dataset, args.vf_architecture, args.vf_variant)
     complete, fmt, missing = mgr.check_cache_exists(cache_dir, n)
     if complete and not args.force_recompute:
         log(f"Flow cache complete ({fmt}), nothing to compute: {cache_dir}")
         return 0
 
-    eng = VideoFlowInference(device, args.fast, args.tile, args.sequence_length, args.vf_dataset,
-                             args.vf_architecture, args.vf_variant)
+    if memflow:     # reference flow_processor.py:64-75: model path defaults to MemFlow_ckpt/MemFlowNet_{stage}.pth
+        eng = MemFlowInference(device, args.model_path or f"MemFlow_ckpt/MemFlowNet_{args.stage}.pth", args.stage,
+                               args.sequence_length)
+    else:
+        eng = VideoFlowInference(device, args.fast, args.tile, args.sequence_length, args.vf_dataset,
+                                 args.vf_architecture, args.vf_variant)
     eng.load_model()
     proc = eng.get_processor()
     clip = proc.upload_clip(frames)
     t0 = time.time()
-    flows = run_sharded(proc, clip, range(n), tile_mode=args.tile, rank=rank, world=world)
+    flows = run_sharded(proc, clip, range(n), tile_mode=args.tile and not memflow, rank=rank, world=world)
     if str(device).startswith('cuda'):
         torch.cuda.synchronize()
     dt = time.time() - t0

@@ -89,8 +89,9 @@ class MemFlowCore:
             return 2 * frames - 1.0
         return frames
 
-    def compute_flow_from_tensor(self, frames_tensor: torch.Tensor) -> torch.Tensor:
-        """[1,T,3,H,W] (0..255, 0..1 or -1..1 floats, any device) -> flow [2,H,W] on the CPU."""
+    def compute_flow_from_tensor(self, frames_tensor: torch.Tensor, keep_on_device: bool = False) -> torch.Tensor:
+        """[1,T,3,H,W] (0..255, 0..1 or -1..1 floats, any device) -> flow [2,H,W] on the CPU
+        (keep_on_device=True, an extension, skips the download for callers that gather on the GPU)."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
         self.validate_input_tensor(frames_tensor)
@@ -99,7 +100,8 @@ class MemFlowCore:
             padder = InputPadder(x.shape)
             x = padder.pad(x)
             _, flow = self.model(x[:, -2:])
-            return padder.unpad(flow[0]).cpu()
+            flow = padder.unpad(flow[0])
+            return flow if keep_on_device else flow.cpu()
 
     def get_memory_usage(self) -> Dict[str, float]:
         if self.device.startswith('cuda'):

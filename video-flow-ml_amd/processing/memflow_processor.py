@@ -65,6 +65,21 @@ class MemFlowProcessor:
         flow = self.core_engine.compute_flow_from_tensor(self.prepare_frame_sequence(frames, frame_idx))
         return flow.permute(1, 2, 0).numpy()
 
+    # -- HBM-resident clips (extension; same fields as compute_optical_flow) -------------------------
+    def upload_clip(self, frames):
+        host = torch.from_numpy(np.stack(frames))
+        dev = self.core_engine.device
+        if dev.startswith('cuda'):
+            host = host.pin_memory()
+        return host.to(dev, non_blocking=True)
+
+    def compute_optical_flow_resident(self, clip, frame_idx, tile=None):
+        """uint8 clip [F,H,W,3] on the device -> flow [H,W,2] on the device (tile is ignored: MemFlow
+        works on full frames, reference :190-247)."""
+        idx = torch.tensor(self.window_indices(frame_idx), device=clip.device)
+        x = clip.index_select(0, idx).permute(0, 3, 1, 2).float().unsqueeze(0)
+        return self.core_engine.compute_flow_from_tensor(x, keep_on_device=True).permute(1, 2, 0)
+
     def compute_optical_flow_with_progress(self, frames, frame_idx, tile_pbar=None) -> np.ndarray:
         if tile_pbar is not None:
             tile_pbar.set_description("MemFlow processing")
