@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 5
+#define VFML_ABI_VERSION 6
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -160,6 +160,12 @@ int vfml_coords_init(float* coords1, int n, int h, int w, void* stream);
  * processing/videoflow_processor.py:185. */
 int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld_mask,
                          int h, int w, float* out, void* stream);
+
+/* One level of the flow-cache LOD pyramid (reference storage/cache_manager.py:77-161): out[y][x] =
+ * 0.5 * (sum of the 2x2 block's in-image vectors) / (number of in-image cells); odd sides are padded
+ * bottom/right with weight 0.  flow: [h][w][2] f32, out: [(h+1)/2][(w+1)/2][2].  Same association as
+ * the reference's per-block np.sum, divisions by 1, 2 or 4: bit-exact. */
+int vfml_flow_lod(const float* flow, int h, int w, float* out, void* stream);
 
 const char* vfml_last_error(void);
 int vfml_abi_version(void);

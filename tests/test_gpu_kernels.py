@@ -431,3 +431,19 @@ def test_upsample_uniform_mask_known_answer(gpu):
     assert torch.allclose(got[8 * 2:8 * 3, 8 * 3:8 * 4, 0], torch.full((8, 8), 8.0), atol=1e-5)   # interior
     assert torch.allclose(got[0:8, 0:8, 0], torch.full((8, 8), 8.0 * 4 / 9), atol=1e-5)         # corner: 4 of 9 taps
     assert (got[..., 1] == 0).all()
+
+
+def test_flow_lod_pyramid_bit_exact_vs_reference_fixture(gpu):
+    """GPU LOD generator == the reference's per-pixel loop (fixtures cut from storage/cache_manager.py)."""
+    import os
+    import numpy as np
+    from storage import LODGenerator
+    A = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_plumbing.npz"))
+    for tag in "abcd":
+        lods = LODGenerator.generate_lods(torch.from_numpy(A[f"lod_{tag}_in"]).cuda(), 4)
+        for k, l in enumerate(lods):
+            assert isinstance(l, np.ndarray) and np.array_equal(l, A[f"lod_{tag}_{k}"]), (tag, k)
+    big = torch.randn(1080, 1920, 2, generator=torch.Generator().manual_seed(41))
+    cpu = LODGenerator.generate_lods(big.numpy(), 5)
+    dev = LODGenerator.generate_lods(big.cuda(), 5)
+    assert all(np.array_equal(a, b) for a, b in zip(cpu, dev))

@@ -332,3 +332,30 @@ def test_memflow_windows_and_errors_match_reference(tmp_path, monkeypatch):
     assert torch.equal(MemFlowCore.normalise(x), torch.tensor([-1.0, 0.0, 1.0]))
     assert torch.equal(MemFlowCore.normalise(x / 255.0 * 1.5), 2 * (x / 255.0 * 1.5) - 1)
     assert torch.equal(MemFlowCore.normalise(x / 255.0), x / 255.0)
+
+
+def test_async_cache_writer_writes_what_the_sync_path_writes(tmp_path):
+    from storage import AsyncFlowCacheWriter, FlowCacheManager
+    rng = np.random.default_rng(5)
+    flows = [rng.standard_normal((33, 47, 2)).astype(np.float32) for _ in range(9)]
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    mgr = FlowCacheManager()
+    for i, f in enumerate(flows):
+        mgr.save_flow_to_cache(f, a, i, "both")
+        mgr.save_flow_lods(mgr.lod_generator.generate_lods(f, 3), a, i)
+    with AsyncFlowCacheWriter(b, "both", workers=4, num_lods=3) as w:
+        for i, f in enumerate(flows):
+            w.submit(f, i)
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(b)) == 9 * (2 + 3)
+    for name in os.listdir(a):
+        if name.endswith(".flo"):
+            assert open(os.path.join(a, name), "rb").read() == open(os.path.join(b, name), "rb").read()
+        else:
+            x, y = np.load(os.path.join(a, name)), np.load(os.path.join(b, name))
+            assert x.files == y.files and all(np.array_equal(x[k], y[k]) and x[k].dtype == y[k].dtype for k in x.files)
+    assert mgr.check_cache_exists(b, 9) == (True, "npz", []) and mgr.check_flow_lods_exist(b, 9, 3)
+    bad = AsyncFlowCacheWriter(str(tmp_path / "file_not_dir"), "npz")
+    open(tmp_path / "file_not_dir", "w").close()
+    bad.submit(flows[0], 0)
+    with pytest.raises(Exception):
+        bad.close()

@@ -27,7 +27,7 @@ import torch
 from config import DeviceManager
 from processing.flow_inference import VideoFlowInference
 from processing.memflow_inference import MemFlowInference
-from storage import FlowCacheManager
+from storage import AsyncFlowCacheWriter, FlowCacheManager
 from vfml import dist as vdist
 from vfml.runner import run_sharded
 
@@ -147,11 +147,12 @@ def main(argv=None):
         log(f"{n} flow fields ({width}x{height}, seq {args.sequence_length}) in {dt:.2f} s = {n / dt:.2f} fields/s "
             f"on {world} GPU(s)")
         save_format = args.save_flow or 'npz'
-        for i in range(n):
-            mgr.save_flow_to_cache(flows[i], cache_dir, i, save_format)
-        log(f"Flow cache written: {cache_dir}")
-        if not args.skip_lods and save_format in ('npz', 'both'):
-            mgr.generate_lods_for_cache(cache_dir, n)
+        t1 = time.time()
+        with AsyncFlowCacheWriter(cache_dir, save_format, workers=min(16, os.cpu_count() or 1),
+                                  num_lods=0 if args.skip_lods else 5, manager=mgr) as writer:
+            for i in range(n):
+                writer.submit(flows[i], i)
+        log(f"Flow cache written: {cache_dir} ({n / max(time.time() - t1, 1e-9):.1f} fields/s incl. LODs)")
         if not args.interactive:
             log("note: video encoding / composition is out of scope for this build; the flow cache is the output")
     if torch.distributed.is_initialized():

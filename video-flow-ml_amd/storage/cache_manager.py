@@ -62,7 +62,11 @@ class FlowFileHandler:
 class LODGenerator:
     @staticmethod
     def generate_lods(flow: np.ndarray, num_lods: int = 5) -> List[np.ndarray]:
-        """[original, lod1, ...]; each level halves H and W (rounding up) and halves the vectors."""
+        """[original, lod1, ...]; each level halves H and W (rounding up) and halves the vectors.
+        A flow tensor that is still on the GPU is reduced there (vfml_flow_lod, bit-identical)."""
+        if torch.is_tensor(flow) and flow.is_cuda and flow.dtype == torch.float32:
+            from vfml import hip
+            return [t.cpu().numpy() for t in hip.flow_lods(flow, num_lods)]
         flow = _to_numpy(flow)
         lods = [flow]
         cur = flow

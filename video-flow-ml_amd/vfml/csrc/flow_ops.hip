@@ -180,6 +180,23 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
   *o = make_float2(ax, ay);
 }
 
+__global__ void flow_lod_kernel(const float2* __restrict__ flow, int h, int w, int ho, int wo, float2* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)ho * wo;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int oy = (int)(i / wo), ox = (int)(i - (int64_t)oy * wo);
+    const int y0 = 2 * oy, x0 = 2 * ox;
+    const bool y1 = y0 + 1 < h, x1 = x0 + 1 < w;
+    // row-major over the block, missing cells contribute 0 with weight 0 (as np.sum(block * weights))
+    const float2 a = flow[(int64_t)y0 * w + x0];
+    const float2 b = x1 ? flow[(int64_t)y0 * w + x0 + 1] : make_float2(0.f, 0.f);
+    const float2 c = y1 ? flow[(int64_t)(y0 + 1) * w + x0] : make_float2(0.f, 0.f);
+    const float2 d = (y1 && x1) ? flow[(int64_t)(y0 + 1) * w + x0 + 1] : make_float2(0.f, 0.f);
+    const float wt = ((1.f + (x1 ? 1.f : 0.f)) + (y1 ? 1.f : 0.f)) + ((y1 && x1) ? 1.f : 0.f);
+    const float sx = ((a.x + b.x) + c.x) + d.x, sy = ((a.y + b.y) + c.y) + d.y;
+    out[i] = make_float2(sx / wt * 0.5f, sy / wt * 0.5f);
+  }
+}
+
 inline int grid_for(int64_t items, int block) {
   int64_t g = (items + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -247,6 +264,16 @@ extern "C" int vfml_coords_update(float* coords1, const float* delta, int n, int
                      reinterpret_cast<hipStream_t>(stream), (f32x4*)coords1, (const f32x4*)delta, h, w, total, flow_a,
                      ld_a, flow_b, ld_b, fmt_b == VFML_FMT_S16 ? 1 : 0);
   return vfml_check_launch("vfml_coords_update");
+}
+
+extern "C" int vfml_flow_lod(const float* flow, int h, int w, float* out, void* stream) {
+  VFML_REQUIRE(flow && out && h > 0 && w > 0, "vfml_flow_lod: bad argument");
+  VFML_REQUIRE((reinterpret_cast<uintptr_t>(flow) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
+               "vfml_flow_lod: 8-byte alignment");
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  hipLaunchKernelGGL(flow_lod_kernel, dim3(grid_for((int64_t)ho * wo, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const float2*)flow, h, w, ho, wo, (float2*)out);
+  return vfml_check_launch("vfml_flow_lod");
 }
 
 extern "C" int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld_mask, int h, int w,

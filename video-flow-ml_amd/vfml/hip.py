@@ -84,10 +84,11 @@ def lib():
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
+    L.vfml_flow_lod.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 5:
+    if L.vfml_abi_version() != 6:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -97,7 +98,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
-    "vfml_convex_upsample", "vfml_last_error", "vfml_abi_version",
+    "vfml_convex_upsample", "vfml_flow_lod", "vfml_last_error", "vfml_abi_version",
 ]
 
 
@@ -303,6 +304,17 @@ def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, fl
     _check(lib().vfml_coords_update(_ptr(_dev(coords1)), _ptr(delta), n, h, w,
                                     _ptr(flow_a, flow_a_off), ld_a, _ptr(flow_b, flow_b_off), ld_b, fmt_b, _stream()),
            "vfml_coords_update")
+
+
+def flow_lods(flow, num_lods=5):
+    """[H,W,2] float32 device tensor -> list of `num_lods` device tensors (level 0 is `flow` itself)."""
+    lods = [_dev(flow.contiguous())]
+    for _ in range(1, num_lods):
+        h, w = lods[-1].shape[:2]
+        out = torch.empty((h + 1) // 2, (w + 1) // 2, 2, device=flow.device, dtype=torch.float32)
+        _check(lib().vfml_flow_lod(_ptr(lods[-1]), h, w, _ptr(out), _stream()), "vfml_flow_lod")
+        lods.append(out)
+    return lods
 
 
 def convex_upsample(coords1, coords_off, ch, mask, mask_off, ld_mask, h, w, out, out_off=0):
