@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--seq", type=int, default=5)
+    ap.add_argument("--workload", default="mof1080p", choices=["mof1080p", "mof4k-tile", "memflow1080p", "bof720p"],
+                    help="mof1080p = BASELINE.json configs[1] (the headline, default); the others are the remaining "
+                         "GPU configs, measured with the same protocol for DESIGN.md (not the driver's line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads for the CPU baseline (0 = this process's CPU share: affinity / cgroup quota, "
@@ -55,6 +58,14 @@ def main():
                          "centre crop of this height (16:9), scaled to full size by the analytic FLOP ratio")
     args = ap.parse_args()
 
+    if args.workload == "mof4k-tile":
+        args.height, args.width = 2160, 3840
+    elif args.workload == "bof720p":
+        args.height, args.width, args.seq = 720, 1280, 9
+    elif args.workload == "memflow1080p":
+        args.seq = 3
+    if args.workload != "mof1080p":
+        args.no_cpu_baseline = True
     from vfml import dist as vdist, get_cfg, hip
     from vfml.synth import synthetic_clip
     from vfml.weights import write_seeded_checkpoint
@@ -77,12 +88,37 @@ def main():
     import contextlib
     import io
     from config import DeviceManager
+    from processing.memflow_processor import MemFlowProcessor
     from processing.videoflow_processor import VideoFlowProcessor
     with contextlib.redirect_stdout(io.StringIO()):
         device_name = DeviceManager().get_device("cuda")
-        proc = VideoFlowProcessor(device_name if world == 1 else f"cuda:{local_rank}", sequence_length=args.seq)
+        device_name = device_name if world == 1 else f"cuda:{local_rank}"
+        if args.workload == "memflow1080p":
+            from vfml.memflow_net import memflow_cfg, seeded_memflow_state_dict
+            os.makedirs("MemFlow_ckpt")
+            torch.save(seeded_memflow_state_dict(memflow_cfg(), 0), "MemFlow_ckpt/MemFlowNet_sintel.pth")
+            proc = MemFlowProcessor(device_name, sequence_length=args.seq)
+        else:
+            arch = "bof" if args.workload == "bof720p" else "mof"
+            if arch == "bof":
+                write_seeded_checkpoint(work, get_cfg(), seed=0, architecture="bof", dataset="things")
+            proc = VideoFlowProcessor(device_name, tile_mode=args.workload == "mof4k-tile", sequence_length=args.seq,
+                                      dataset="things" if arch == "bof" else "sintel", architecture=arch)
         proc.load_model()
     os.chdir(cwd)
+    tiles = proc.calculate_tile_grid(args.width, args.height)[4] if args.workload == "mof4k-tile" else [None]
+
+    def run_fields(clip, idxs, dst):
+        """Flow fields of frames `idxs` into dst[k] ([H,W,2] each, on the device); in --tile mode
+        tile-major (all fields of tile 0, then tile 1, ...: the order vfml.runner uses), so that
+        consecutive items share their crop's cached frames."""
+        for t in tiles:
+            for k, i in enumerate(idxs):
+                f = proc.compute_optical_flow_resident(clip, i, tile=t)
+                if t is None:
+                    dst[k].copy_(f)
+                else:
+                    dst[k, t['y']:t['y'] + t['height'], t['x']:t['x'] + t['width']].copy_(f)
 
     # -- synthetic clip, uploaded once ---------------------------------------------------------
     K, Wm, T = args.steps, args.warmup, args.seq
@@ -97,16 +133,15 @@ def main():
     fields = [half + i for i in range(per_rank)]          # local indices with a full window
     torch.cuda.synchronize()
 
-    for i in fields[:Wm]:
-        proc.compute_optical_flow_resident(clip, i)
+    out = torch.empty(max(K, Wm), args.height, args.width, 2, device=dev)
+    run_fields(clip, fields[:Wm], out)
     torch.cuda.synchronize()
     vdist.barrier(dev)
 
-    out = torch.empty(K, args.height, args.width, 2, device=dev)
+    out = out[:K]
     hip.profile_begin()
     t0 = time.perf_counter()
-    for k, i in enumerate(fields[Wm:]):
-        out[k].copy_(proc.compute_optical_flow_resident(clip, i))
+    run_fields(clip, fields[Wm:], out)
     torch.cuda.synchronize()
     t_compute = time.perf_counter() - t0
     tg = time.perf_counter()
@@ -124,8 +159,11 @@ def main():
     assert gathered is not None and len(gathered) == world
 
     total_fields = K * world
+    core = proc.core if hasattr(proc, "core") else proc.core_engine
+    depth = core.cfg.decoder_depth
     result = {
-        "metric": "flow-fields/sec @1080p seq5 MOF_sintel",
+        "metric": "flow-fields/sec @1080p seq5 MOF_sintel" if args.workload == "mof1080p"
+                  else f"flow-fields/sec {args.workload}",
         "value": total_fields / elapsed,
         "unit": "flow-fields/s",
         "n_gpus": world, "steps": K, "warmup": Wm,
@@ -134,10 +172,12 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"f16x3": "f16x3 (split-f16 MFMA, f32 accumulate, fp32-grade)", "f32": "f32"}[
-            getattr(proc.core.cfg, "precision", "f16x3")],
+            getattr(core.cfg, "precision", "f16x3")],
         "data": "synthetic",
-        "config": {"workload": f"MOF_sintel seq_len={T} {args.width}x{args.height} synthetic clip, "
-                               f"decoder_depth={proc.core.cfg.decoder_depth}, seeded weights",
+        "config": {"workload": {"mof1080p": "MOF_sintel", "mof4k-tile": "MOF_sintel --tile (6 tiles/frame)",
+                                "memflow1080p": "MemFlowNet_sintel (pair path)", "bof720p": "BOF_things"}[args.workload]
+                               + f" seq_len={T} {args.width}x{args.height} synthetic clip, decoder_depth={depth}, "
+                                 f"seeded weights",
                    "fields_per_gpu": K, "clip_frames_per_gpu": nframes, "parallelism": f"frames-dp{world}",
                    "inputs": "uint8 clip resident in HBM", "outputs": "[H,W,2] f32 in HBM, gathered to rank 0"},
         "compute_ms_per_step": 1000.0 * t_compute / K,

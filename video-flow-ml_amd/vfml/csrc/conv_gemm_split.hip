@@ -109,7 +109,7 @@ __device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float
 // 16 B of hi halves then 16 B of lo halves), so the two 16-byte loads of a unit ARE its hi and lo
 // LDS images and no conversion happens in the loop.
 template <int BN, int WM, int WN, bool BIGC, bool IN16>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void conv_gemm_split_kernel(const SplitArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const SplitArgs a) {
   constexpr int NT = WM * WN * 64;  // threads: 256 (4 waves) or 512 (8 waves, finer MFMA interleave per SIMD)
   constexpr int LR = NT / 4;        // rows covered by one pass of the loader (4 k-groups per row)
   constexpr int TM = BM / (WM * 32);
@@ -334,18 +334,29 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void conv_gemm_split_ker
   load_tile(st1, BK);
   store_tile(st0, 0);
   __syncthreads();
+  // -DVFML_EXPERIMENT_NOLOAD builds a timing-only variant without the in-loop loads and LDS writes
+  // (garbage results): the MFMA + fragment-read phase alone runs at 500-570 TFLOP/s algorithmic vs
+  // 285-310 with staging (tools/conv_microbench.py; DESIGN.md "what bounds the conv kernel").
   for (int kt = 0; kt < nk; kt += 2) {
+#ifndef VFML_EXPERIMENT_NOLOAD
     load_tile(st0, (kt + 2) * BK);
+#endif
     __builtin_amdgcn_sched_barrier(0);   // loads first ...
     compute(0);
     __builtin_amdgcn_sched_barrier(0);   // ... their consumers (split + LDS write) only after the MFMAs
+#ifndef VFML_EXPERIMENT_NOLOAD
     store_tile(st1, 1);
+#endif
     __syncthreads();
+#ifndef VFML_EXPERIMENT_NOLOAD
     load_tile(st1, (kt + 3) * BK);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     compute(1);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef VFML_EXPERIMENT_NOLOAD
     store_tile(st0, 0);
+#endif
     __syncthreads();
   }
 

@@ -42,9 +42,14 @@ def shard_bounds(num_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def work_items(frame_indices, tiles_per_frame=1):
-    """Flattened (frame, tile) list, frame-major — the order the reference's serial loops visit them
-    (flow_processor.py:959 over frames, videoflow_processor.py:258 over tiles)."""
+def work_items(frame_indices, tiles_per_frame=1, tile_major=False):
+    """Flattened (frame, tile) list.  Frame-major is the order the reference's serial loops visit them
+    (flow_processor.py:959 over frames, videoflow_processor.py:258 over tiles); tile-major (all frames
+    of tile 0, then tile 1, ...) computes the same items but lets consecutive items share T-1 frames
+    of the same crop, which is what the engine's sliding-window caches key on."""
+    frame_indices = list(frame_indices)
+    if tile_major:
+        return [(f, t) for t in range(tiles_per_frame) for f in frame_indices]
     return [(f, t) for f in frame_indices for t in range(tiles_per_frame)]
 
 

@@ -26,7 +26,7 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     frame_indices = list(frame_indices)
     F, H, W = clip.shape[0], clip.shape[1], clip.shape[2]
     tiles = _tiles(proc, W, H, tile_mode)
-    items = vdist.work_items(frame_indices, len(tiles))
+    items = vdist.work_items(frame_indices, len(tiles), tile_major=True)   # keeps the per-crop caches hot
     bounds = [vdist.shard_bounds(len(items), r, world) for r in range(world)]
     sizes = [sum(item_numel(H, W, tiles[t]) for _, t in items[lo:hi]) for lo, hi in bounds]
     lo, hi = bounds[rank]
