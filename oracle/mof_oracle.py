@@ -173,10 +173,15 @@ class MotionEncoder(nn.Module):
         self.convf1 = nn.Conv2d(4, 128, 7, padding=3)
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(192 + 64, 128 - 4, 3, padding=1)
+        self.sel = None
 
     def forward(self, fflow, bflow, fcorr, bcorr):
         flow = torch.cat([fflow, bflow], dim=1)
-        cor = F.relu(self.convc1(torch.cat([fcorr, bcorr], dim=1)))
+        w = self.convc1.weight
+        if self.sel is not None:    # --fast: a sub-window / sub-pyramid of the trained lookup's input columns
+            half = w.shape[1] // 2
+            w = torch.cat([w[:, self.sel], w[:, half + self.sel]], dim=1)
+        cor = F.relu(F.conv2d(torch.cat([fcorr, bcorr], dim=1), w, self.convc1.bias))
         cor = F.relu(self.convc2(cor))
         flo = F.relu(self.convf1(flow))
         flo = F.relu(self.convf2(flo))
@@ -260,8 +265,15 @@ class MOFNetOracle(nn.Module):
         self.hidden_dim = self.context_dim = cfg.feat_dim // 2
         self.fnet = BasicEncoder(cfg.feat_dim)
         self.cnet = BasicEncoder(cfg.feat_dim)
-        cor_planes = cfg.corr_levels * (2 * cfg.corr_radius + 1) ** 2
-        self.update_block = MOFUpdateBlock(cor_planes, self.hidden_dim)
+        # checkpoint shapes are those of the base 4-level, radius-4 lookup; a smaller configured lookup
+        # (the reference's --fast, processing/videoflow_core.py:91-94) uses the matching input columns
+        BL, BR = 4, 4
+        self.update_block = MOFUpdateBlock(BL * (2 * BR + 1) ** 2, self.hidden_dim)
+        if (cfg.corr_levels, cfg.corr_radius) != (BL, BR):
+            bw, d = 2 * BR + 1, BR - cfg.corr_radius
+            self.update_block.encoder.sel = torch.tensor(
+                [l * bw * bw + (i + d) * bw + (j + d) for l in range(cfg.corr_levels)
+                 for i in range(2 * cfg.corr_radius + 1) for j in range(2 * cfg.corr_radius + 1)])
 
     @torch.no_grad()
     def forward(self, images, data=None, return_lowres=False):

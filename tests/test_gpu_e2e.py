@@ -148,3 +148,34 @@ def test_cli_on_gpu_writes_the_cache_the_api_would(gpu, tmp_path, monkeypatch, m
     for i in (0, 2, 4):
         got = np.load(cache / f"flow_frame_{i:06d}.npz")["flow"]
         assert np.array_equal(got, eng.compute_optical_flow(frames, i)), i
+
+
+def test_longest_window_and_reference_api_with_padding(gpu, tmp_path, monkeypatch):
+    """seq_len 10 (the reference's maximum, processing/videoflow_processor.py:357-361: 8 centre frames =
+    the lookup kernel's map limit) on a frame whose sides are not multiples of 8, through the reference
+    API path (host floats, InputPadder, index pick) with --fast."""
+    import contextlib
+    import io
+    import numpy as np
+    from oracle import mof_oracle as mo
+    from processing.flow_inference import VideoFlowInference
+    from vfml import get_cfg
+    from vfml.synth import synthetic_clip
+    from vfml.weights import seeded_state_dict, write_seeded_checkpoint
+    write_seeded_checkpoint(str(tmp_path), get_cfg(), seed=0)
+    monkeypatch.chdir(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = VideoFlowInference("cuda", fast_mode=True, sequence_length=10)
+        eng.load_model()
+    assert eng.get_model_info()["config"] == {"decoder_depth": 6, "corr_levels": 3, "corr_radius": 3}
+    frames = synthetic_clip(10, 100, 132)
+    got = eng.compute_optical_flow(frames, 5)
+    assert got.shape == (100, 132, 2)
+    ocfg = mo.get_cfg()
+    ocfg.decoder_depth, ocfg.corr_levels, ocfg.corr_radius = 6, 3, 3
+    ora = mo.build_network(ocfg).eval()
+    ora.load_state_dict(seeded_state_dict(get_cfg(), 0))
+    x = eng.prepare_frame_sequence(frames, 5).cpu()
+    pad = mo.InputPadder(x.shape[-2:])
+    ref = pad.unpad(ora(pad.pad(x), {})[0])[0, 8].permute(1, 2, 0).numpy()      # shape[1]//2 of 16 flows
+    assert np.sqrt(((got - ref) ** 2).sum(-1)).mean() < EPE_TOL

@@ -112,3 +112,20 @@ def test_seeded_state_dict_is_deterministic_and_loads_strictly():
     net = mo.build_network(mo.get_cfg())
     net.load_state_dict(a, strict=True)
     assert len(conv_spec(cfg)) * 2 == len(a)
+
+
+def test_fast_mode_lookup_is_a_channel_subset_of_the_base_lookup():
+    """--fast (3 levels, radius 3) on a checkpoint trained for the base lookup: the smaller lookup's
+    channels are exactly `corr_channel_subset` of the base one's, which is what lets the engine and the
+    oracle use the matching input columns of convc1 (vfml/weights.py)."""
+    import torch
+    from oracle import mof_oracle as mo
+    from vfml.weights import corr_channel_subset
+    g = torch.Generator().manual_seed(3)
+    f1, f2 = torch.randn(1, 32, 16, 24, generator=g), torch.randn(1, 32, 16, 24, generator=g)
+    coords = mo.coords_grid(1, 16, 24, torch.float32) + torch.randn(1, 2, 16, 24, generator=g) * 3
+    base = mo.CorrBlock(f1, f2, 4, 4)(coords)
+    small = mo.CorrBlock(f1, f2, 3, 3)(coords)
+    sel = torch.tensor(corr_channel_subset(3, 3))
+    assert small.shape[1] == sel.numel() == 147
+    assert torch.equal(small, base[:, sel])

@@ -76,8 +76,8 @@ class MemFlowProcessor:
     def compute_optical_flow_resident(self, clip, frame_idx, tile=None):
         """uint8 clip [F,H,W,3] on the device -> flow [H,W,2] on the device (tile is ignored: MemFlow
         works on full frames, reference :190-247)."""
-        idx = torch.tensor(self.window_indices(frame_idx), device=clip.device)
-        x = clip.index_select(0, idx).permute(0, 3, 1, 2).float().unsqueeze(0)
+        from vfml.network import take_frames
+        x = take_frames(clip, self.window_indices(frame_idx)).permute(0, 3, 1, 2).float().unsqueeze(0)
         return self.core_engine.compute_flow_from_tensor(x, keep_on_device=True).permute(1, 2, 0)
 
     def compute_optical_flow_with_progress(self, frames, frame_idx, tile_pbar=None) -> np.ndarray:

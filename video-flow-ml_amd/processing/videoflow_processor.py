@@ -136,8 +136,9 @@ class VideoFlowProcessor:
         Same window, same /255, same network and index pick as compute_optical_flow; the u8->float
         conversion runs inside the engine's first kernel."""
         self._require_model()
+        from vfml.network import take_frames
         frame_ids = self.window_indices(clip.shape[0], frame_idx)
-        win = clip.index_select(0, torch.tensor(frame_ids, device=clip.device))
+        win = take_frames(clip, frame_ids)        # a view in the steady state: no index upload, no sync
         rect = None
         if tile is not None:
             rect = (tile['x'], tile['y'], tile['width'], tile['height'])

@@ -114,6 +114,7 @@ class MemFlowNetHIP(MOFNetHIP):
                     cout = self._cout_of[name] if name in self._cout_of else b.numel()
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
                     P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
+        self._gamma = float(self._param(ub).gamma.item())   # read once per load: .item() synchronises
         self._packed, self._packed_key = P, key
         self._packed_serial += 1
         self._feat_cache.clear()
@@ -147,7 +148,7 @@ class MemFlowNetHIP(MOFNetHIP):
         cor = L * (2 * R + 1) ** 2
         cor_p = (cor + 7) // 8 * 8 if split else (cor + 3) // 4 * 4
         ub = "update_block"
-        gamma = float(self._param(ub).gamma.item())
+        gamma = self._gamma
 
         with torch.cuda.device(dev):
             hl, wl = [h], [w]

@@ -25,7 +25,16 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .weights import conv_spec, pack_conv_weight
+from .weights import conv_spec, corr_channel_subset, pack_conv_weight
+
+
+def take_frames(src, idx):
+    """src[idx] along dim 0 without a host->device index upload (a pageable H2D copy would make the
+    host wait for all queued GPU work): a view when idx is a contiguous run, device-side copies otherwise."""
+    idx = list(idx)
+    if all(b == a + 1 for a, b in zip(idx, idx[1:])):
+        return src[idx[0]:idx[0] + len(idx)]
+    return torch.stack([src[i] for i in idx])
 
 
 class _Holder(nn.Module):
@@ -81,12 +90,16 @@ class MOFNetHIP(_Holder):
             leaf = self._param(name)
             w = leaf.weight.detach().to(device=device, dtype=torch.float32)
             if name.endswith(".encoder.convc1"):
-                # each direction's lookup block is padded to whole float4s / split-row units (zero weights)
-                cor = cin // 2
+                # input columns of the configured lookup (a sub-window / sub-pyramid of the checkpoint's
+                # base lookup under --fast); each direction's block is padded to whole float4s /
+                # split-row units with zero weights
+                base = cin // 2
+                sel = torch.tensor(corr_channel_subset(self.cfg.corr_levels, self.cfg.corr_radius), device=device)
+                cor = sel.numel()
                 cor_p = (cor + 7) // 8 * 8 if split else (cor + 3) // 4 * 4
                 wp = torch.zeros(cout, 2 * cor_p, 1, 1, device=device)
-                wp[:, :cor] = w[:, :cor]
-                wp[:, cor_p:cor_p + cor] = w[:, cor:]
+                wp[:, :cor] = w[:, sel]
+                wp[:, cor_p:cor_p + cor] = w[:, base + sel]
                 w = wp
             if name.endswith(".tprop"):
                 # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
@@ -263,8 +276,7 @@ class MOFNetHIP(_Holder):
         if todo:
             m, Pn = len(todo), hl[0] * wl[0]
             frames = self._buf("frames", m * H * W * 4, dev)
-            sub = src if m == src.shape[0] else src.index_select(0, torch.tensor(todo, device=dev))
-            hip.frames_to_nhwc4(sub.contiguous(), m, H, W, float(self.cfg.input_scale), float(self.cfg.input_shift),
+            hip.frames_to_nhwc4(take_frames(src, todo).contiguous(), m, H, W, float(self.cfg.input_scale), float(self.cfg.input_shift),
                                 frames)
             fmap = torch.empty(m * Pn * D, device=dev)          # owned by the cache entries (views)
             self._encoder("fnet", frames, m, H, W, P, dev, fmap, D, 0, hip.EPI_NONE, 0)
@@ -302,7 +314,7 @@ class MOFNetHIP(_Holder):
         if todo:
             m = len(todo)
             frames = self._buf("frames", m * H * W * 4, dev)
-            hip.frames_to_nhwc4(src.index_select(0, torch.tensor(todo, device=dev)).contiguous(), m, H, W,
+            hip.frames_to_nhwc4(take_frames(src, todo).contiguous(), m, H, W,
                                 float(self.cfg.input_scale), float(self.cfg.input_shift), frames)
             ctx = torch.empty(m * Pn * 256, device=dev)
             AF = hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32

@@ -27,9 +27,26 @@ def _encoder_spec(prefix, out_dim):
     return s
 
 
+BASE_CORR_LEVELS, BASE_CORR_RADIUS = 4, 4   # what a checkpoint's correlation-input weights are shaped for
+
+
+def corr_channel_subset(levels, radius, base_levels=BASE_CORR_LEVELS, base_radius=BASE_CORR_RADIUS):
+    """Channels of a base (4-level, radius-4) lookup that a smaller lookup produces, in its own order:
+    level l < levels, window offsets within +-radius (the centred sub-window).  The reference's --fast
+    mode lowers corr_levels / corr_radius on the cfg of an already-trained network
+    (processing/videoflow_core.py:91-94); the checkpoint keeps its shapes, the engine uses the matching
+    input columns of the first motion-encoder convolution."""
+    if levels > base_levels or radius > base_radius:
+        raise ValueError(f"corr_levels <= {base_levels} and corr_radius <= {base_radius} required")
+    bw, d = 2 * base_radius + 1, base_radius - radius
+    return [l * bw * bw + (i + d) * bw + (j + d)
+            for l in range(levels) for i in range(2 * radius + 1) for j in range(2 * radius + 1)]
+
+
 def conv_spec(cfg):
-    """[(name, cout, cin, kh, kw)] for every convolution, in state-dict order."""
-    cor = cfg.corr_levels * (2 * cfg.corr_radius + 1) ** 2
+    """[(name, cout, cin, kh, kw)] for every convolution, in state-dict order (checkpoint shapes: the
+    correlation input is always the base 4-level radius-4 lookup)."""
+    cor = BASE_CORR_LEVELS * (2 * BASE_CORR_RADIUS + 1) ** 2
     hid = cfg.feat_dim // 2
     s = _encoder_spec("fnet", cfg.feat_dim) + _encoder_spec("cnet", cfg.feat_dim)
     ub = "update_block"
