@@ -188,7 +188,7 @@ def main():
     if prof:
         name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        split = "split" in name
+        split = "split" in name or "dma" in name      # both are split-f16 kernels (3 f16 MFMAs per product)
         peak = F16_MATRIX_PEAK_TFLOPS / 3.0 if split else F32_MATRIX_PEAK_TFLOPS
         result["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 6
+#define VFML_ABI_VERSION 7
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -82,8 +82,16 @@ int vfml_conv2d(const vfml_conv_desc* d, void* stream);
  * of 32; the kernel divides the accumulator by w_scale.  Activations stay fp32 in HBM and are split
  * while staged into LDS. */
 int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
-                      int in_fmt, int out_fmt, int aux_fmt, void* stream);
-/* in_fmt: format of in0/in1; out_fmt: of out; aux_fmt: of aux0/aux1 (VFML_FMT_*). */
+                      int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream);
+/* in_fmt: format of in0/in1; out_fmt: of out; aux_fmt: of aux0/aux1 (VFML_FMT_*).
+ * k_order: order of the K axis of the weight planes.
+ *   VFML_KORDER_TAP     [cout][ky][kx][ci], kp = kh*kw*(c0+c1) rounded up to 32 (as d->weight).
+ *   VFML_KORDER_CBLOCK  [cout][ci/32][ky][kx][ci%32], channels zero padded to a multiple of 32,
+ *                       kp = kh*kw*roundup32(c0+c1); split-row sources only.  All taps of one
+ *                       32-channel block are consecutive K steps, so the kh*kw reads of an input line
+ *                       happen while it is still in L2 (tap-major order re-reads it ctot/32 steps later,
+ *                       from the Infinity Cache or HBM).  For 1x1 convolutions the two orders coincide. */
+enum { VFML_KORDER_TAP = 0, VFML_KORDER_CBLOCK = 1 };
 
 /* f32 rows [rows][c] (row stride ld_src floats) -> split rows [rows][ld_dst] (VFML_FMT_S16); c % 4 == 0. */
 int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream);

@@ -25,14 +25,17 @@ PRECISIONS = ["f32", "f16x3"]     # exact f32 MFMA / split-f16 (3 f16 MFMAs per 
 CONV_TOL = {"f32": 2e-6, "f16x3": 5e-6}
 
 
-def as_weight(flat, cout, precision):
-    """flat [cout][K] f32 (host or device) -> what hip.conv2d takes for that precision."""
+def as_weight(flat, cout, precision, order=0):
+    """flat [cout][K] f32 (host or device) -> what hip.conv2d takes for that precision; `order` says
+    which K order `flat` was packed in (hip.KORDER_*)."""
     from vfml import hip
     flat = flat.cuda().contiguous()
     if precision == "f32":
         return flat
-    return hip.SplitWeight(cout, flat.numel() // cout, flat.device).fill(
+    w = hip.SplitWeight(cout, flat.numel() // cout, flat.device).fill(
         flat, scale=hip.SplitWeight.auto_scale(float(flat.abs().max())))
+    w.order = order
+    return w
 
 
 @pytest.mark.parametrize("cin,cout,kh,kw,stride,ph,pw,H,W,n", [
@@ -122,6 +125,32 @@ def test_conv2d_as_gemm_correlation(gpu, precision):
     assert (got[:, S:] == 0).all()
 
 
+@pytest.mark.parametrize("bias,epi", [(False, "none"), (True, "relu")])
+def test_wide_gemm_persistent_path(gpu, bias, epi):
+    """Split-row rows x wide plain-f32 output: the persistent form of the LDS-DMA kernel (more tiles than
+    resident workgroups, ragged last row and column tiles, 16-byte row stores, optional bias)."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(21)
+    P, S, D = 1300, 6404, 256
+    f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
+    b = torch.randn(S, generator=g) if bias else None
+    ld = (S + 31) // 32 * 32
+    x16 = torch.empty(P * D, device=gpu)
+    hip.to_s16(f1.cuda().reshape(-1), P, D, D, x16, D)
+    out = torch.full((P * ld,), 7.0, device=gpu)
+    hip.conv2d(x16, D, D, 1, 1, P, as_weight(f2.reshape(-1), S, "f16x3"), b.cuda() if bias else None, S, 1, 1, out, ld,
+               out_scale=1.0 / 16.0, epilogue=hip.EPI_RELU if epi == "relu" else hip.EPI_NONE, in_fmt=hip.FMT_S16)
+    ref = f1.double() @ f2.double().t()
+    if bias:
+        ref = ref + b.double()
+    ref = ref / 16.0
+    if epi == "relu":
+        ref = ref.clamp_min(0)
+    got = out.view(P, ld).cpu()
+    assert rel_err(got[:, :S], ref.float()) < CONV_TOL["f16x3"]
+    assert (got[:, S:] == 7.0).all()          # nothing written past cout
+
+
 def s16_decode(flat, rows, ld, c):
     """split rows (FMT_S16) device buffer -> f32 [rows, c] on the host."""
     u = flat.view(torch.float16).view(rows, ld // 8, 2, 8).float().cpu()
@@ -139,9 +168,13 @@ def test_to_s16_roundtrip(gpu):
     assert ((rec[:, :20] - x).abs() <= 2.0 ** -21 * x.abs() + 2.0 ** -24).all()
 
 
-@pytest.mark.parametrize("cin,cout,kh,kw", [(64, 128, 3, 3), (256, 124, 3, 3), (128, 64, 1, 1), (512, 256, 1, 5)])
-def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw):
-    """Split-row (S16) activations in, split-row activations out == the f32-in/f32-out result."""
+@pytest.mark.parametrize("cblock", [False, True])
+@pytest.mark.parametrize("cin,cout,kh,kw", [(64, 128, 3, 3), (256, 124, 3, 3), (128, 64, 1, 1), (512, 256, 1, 5),
+                                            (72, 192, 3, 3), (256, 4, 3, 3), (40, 36, 5, 1), (656, 256, 1, 1)])
+def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw, cblock):
+    """Split-row (S16) activations in, split-row activations out == the f32-in/f32-out result, with
+    the weights in tap order and in channel-block order (incl. channel counts that are not multiples
+    of 32 and every tile width of the LDS-DMA kernel)."""
     from vfml import hip
     from vfml.weights import pack_conv_weight
     g = torch.Generator().manual_seed(13)
@@ -150,7 +183,7 @@ def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw):
     wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
     b = torch.randn(cout, generator=g)
     ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=(kh // 2, kw // 2))).float()
-    w = as_weight(pack_conv_weight(wt), cout, "f16x3")
+    w = as_weight(pack_conv_weight(wt, cblock=cblock), cout, "f16x3", order=int(cblock))
     x16 = torch.empty(n * H * W * cin, device=gpu)
     hip.to_s16(nhwc(x), n * H * W, cin, cin, x16, cin)
     ldo = (cout + 7) // 8 * 8 + 8
@@ -163,7 +196,8 @@ def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw):
     assert rel_err(got, ref) < CONV_TOL["f16x3"]
 
 
-def test_gru_epilogues_in_split_rows(gpu):
+@pytest.mark.parametrize("cblock", [False, True])
+def test_gru_epilogues_in_split_rows(gpu, cblock):
     """The engine's state buffer in split rows: gates read h / z as S16 aux operands, write S16."""
     from vfml import hip
     from vfml.weights import pack_conv_weight
@@ -183,10 +217,12 @@ def test_gru_epilogues_in_split_rows(gpu):
     G = torch.zeros(P * LD, device=gpu)
     hip.to_s16(nhwc(hx), P, 512, 512, G, LD, dst_off=HH)
     S = hip.FMT_S16
-    wzr = as_weight(torch.cat([pack_conv_weight(wz), pack_conv_weight(wr)]), 256, "f16x3")
+    wzr = as_weight(torch.cat([pack_conv_weight(wz, cblock=cblock), pack_conv_weight(wr, cblock=cblock)]), 256, "f16x3",
+                    order=int(cblock))
     hip.conv2d(G, 512, LD, n, H, W, wzr, torch.cat([bz, br]).cuda(), 256, 5, 1, G, LD, in0_off=HH, out_off=Z, pad_h=2,
                epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=LD, aux0_off=HH, in_fmt=S, out_fmt=S, aux_fmt=S)
-    hip.conv2d(G, 128, LD, n, H, W, as_weight(pack_conv_weight(wq), 128, "f16x3"), bq.cuda(), 128, 5, 1, G, LD,
+    hip.conv2d(G, 128, LD, n, H, W, as_weight(pack_conv_weight(wq, cblock=cblock), 128, "f16x3", order=int(cblock)),
+               bq.cuda(), 128, 5, 1, G, LD,
                in0_off=RH, out_off=HH, in1=G, c1=384, ld1=LD, in1_off=X, pad_h=2, epilogue=hip.EPI_GRU_Q,
                aux0=G, ld_aux0=LD, aux0_off=Z, aux1=G, ld_aux1=LD, aux1_off=HH, in_fmt=S, out_fmt=S, aux_fmt=S)
     got = s16_decode(G, P, LD, LD).view(n, H, W, LD).permute(0, 3, 1, 2)

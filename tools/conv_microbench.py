@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, 
 import torch
 from vfml import hip
 
-def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=False):
+def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=False, cblock=None, gemm=False):
+    cblock = (os.environ.get("MB_CBLOCK", "1") == "1") if cblock is None else cblock
     ld = ld or cin
     x = torch.randn(n * h * w * ld, device="cuda")
     fmt = hip.FMT_S16 if s16 else hip.FMT_F32
@@ -16,11 +17,21 @@ def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=
         name += " [S16]"
     wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
     b = torch.randn(cout, device="cuda")
-    wobj = wt if prec == "f32" else hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
+    if prec != "f32" and s16 and cblock:
+        from vfml.weights import pack_conv_weight
+        wc = pack_conv_weight(wt.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2), cblock=True)
+        wobj = hip.SplitWeight(cout, wc.numel() // cout, x.device).fill(wc, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
+        wobj.order = hip.KORDER_CBLOCK
+        name += " cb"
+    else:
+        wobj = wt if prec == "f32" else hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
     out = torch.empty(n * h * w * cout, device="cuda")
     def run():
-        hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
-                   in_fmt=fmt, out_fmt=fmt)
+        if gemm:     # as the correlation volume is built: no bias, no activation, plain f32 out
+            hip.conv2d(x, cin, ld, n, h, w, wobj, None, cout, kh, kw, out, cout, out_scale=1.0 / 16.0, in_fmt=fmt)
+        else:
+            hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
+                       in_fmt=fmt, out_fmt=fmt)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,8 +49,8 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s16":
     bench("3x3 c256->256", 3, 135, 240, 256, 256, 3, 3, s16=True)
     bench("3x3 c256->192", 3, 135, 240, 256, 192, 3, 3, s16=True)
     bench("1x1 c656->256", 3, 135, 240, 656, 256, 1, 1, s16=True)
-    bench("gemm 32400x32400x256", 1, 1, 32400, 256, 32400, 1, 1, reps=5, s16=True)
-    bench("gemm 32400x8040x256", 1, 1, 32400, 256, 8040, 1, 1, reps=5, s16=True)
+    bench("gemm 32400x32400x256", 1, 1, 32400, 256, 32400, 1, 1, reps=5, s16=True, gemm=True)
+    bench("gemm 32400x8040x256", 1, 1, 32400, 256, 8040, 1, 1, reps=5, s16=True, gemm=True)
     sys.exit(0)
 
 if __name__ == "__main__":

@@ -65,6 +65,11 @@ struct SplitArgs {
   int mtiles, ntiles;
   int vec_ok;  // out/aux/bias 16-byte aligned and ldo, ld_aux % 4 == 0 -> float4 epilogue
   int out16, aux16;   // output / aux operands in the split-row format (VFML_FMT_S16)
+  // LDS-DMA kernel: both weight planes through one descriptor at wbase (byte offsets of the planes, extent)
+  const char* wbase; int whi_off, wlo_off, bytesb;
+  int korder;   // VFML_KORDER_*
+  int direct;   // LDS-DMA kernel: plain f32 output written straight from the accumulators
+  int pointwise;  // 1x1 / stride 1 / no padding
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -99,6 +104,119 @@ __device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float
     case VFML_EPI_GRU_Q: return (1.f - x0) * x1 + x0 * tanhf(v);
     case VFML_EPI_ADD_AUX: return x0 + v;
     default: return v;
+  }
+}
+
+// accumulator tiles of one wave -> the workgroup's fp32 tile in LDS (row stride LDC floats)
+template <int TM, int TN, int LDC>
+__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[TM][TN], float* sC, int row0, int col0, int r, int half) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int col = col0 + j * 32 + r;
+        sC[row * LDC + col] = acc[i][j][e];
+      }
+}
+
+// the LDS tile -> global rows: bias, addend, activation / GRU gate math, f32 or split-row stores
+template <int BN, int NT>
+__device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* sC, int m0, int n0, int t,
+                                              int nrows = BM, int rstride = 32, int roff = 0) {
+  // LDS row `row` is output pixel m0 + (row / 32) * rstride + roff + row % 32 (identity by default; the
+  // LDS-DMA kernel passes the tile through in slabs of one 32-row block per wave row)
+  constexpr int LDC = BN + 4;
+  // 8 channels (one split-row unit) per thread, as two quads
+  constexpr int C8 = BN / 8;
+  constexpr int RPP = NT / C8;       // rows per pass
+  const int c8 = t % C8;
+  const int gcol = n0 + c8 * 8;
+  if (gcol >= a.cout) return;
+  const int epi = a.epilogue;
+  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (a.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (gcol + e < a.cout) bias4[e >> 2][e & 3] = a.bias[gcol + e];
+  }
+  // reads 4 channels at (row, col) of an aux operand in either format
+  auto aux4 = [&](const float* base, int ld, int64_t row, int col) -> f32x4 {
+    f32x4 x;
+    if (a.aux16) {
+      const char* u = reinterpret_cast<const char*>(base + row * ld + (col & ~7)) + (col & 4) * 2;
+      const h16x2 h0 = *reinterpret_cast<const h16x2*>(u), h1 = *reinterpret_cast<const h16x2*>(u + 4);
+      const h16x2 l0 = *reinterpret_cast<const h16x2*>(u + 16), l1 = *reinterpret_cast<const h16x2*>(u + 20);
+      x[0] = (float)h0[0] + (float)l0[0];
+      x[1] = (float)h0[1] + (float)l0[1];
+      x[2] = (float)h1[0] + (float)l1[0];
+      x[3] = (float)h1[1] + (float)l1[1];
+    } else if (a.vec_ok) {
+      x = *reinterpret_cast<const f32x4*>(base + row * ld + col);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = base[row * ld + col + e];
+    }
+    return x;
+  };
+  for (int row = t / C8; row < nrows; row += RPP) {
+    const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
+    if (grow >= a.M) continue;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = gcol + 4 * q;
+      if (col >= a.cout) break;
+      const bool lowhalf = col < a.split;   // split is a multiple of 4: a quad never straddles it
+      const int nvalid = a.cout - col >= 4 ? 4 : a.cout - col;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4 * q]);
+      f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.addend) {
+        if (nvalid == 4 && a.vec_ok) {
+          add4 = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + col);
+        } else {
+          for (int e = 0; e < nvalid; ++e) add4[e] = a.addend[(int64_t)grow * a.ld_addend + col + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + add4[e] + bias4[q][e]) * a.out_scale;
+      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+      if (nvalid == 4) {
+        if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0 = aux4(a.aux0, a.ld_aux0, grow, col - a.split);
+        if (epi == VFML_EPI_GRU_Q) {
+          x0 = aux4(a.aux0, a.ld_aux0, grow, col);
+          x1 = aux4(a.aux1, a.ld_aux1, grow, col);
+        }
+        if (epi == VFML_EPI_ADD_AUX) x0 = aux4(a.aux0, a.ld_aux0, grow, col);
+      } else {
+        for (int e = 0; e < nvalid; ++e) {   // ragged tail: f32 operands only (host check)
+          if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e - a.split];
+          if (epi == VFML_EPI_GRU_Q) {
+            x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
+            x1[e] = a.aux1[(int64_t)grow * a.ld_aux1 + col + e];
+          }
+          if (epi == VFML_EPI_ADD_AUX) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = epi1(v[e], epi, lowhalf, x0[e], x1[e]);
+      if (a.out16) {
+        // hi quad at unit + 8q bytes, lo quad at unit + 16 + 8q (cout % 4 == 0, host check)
+        U8 hi, lo;
+        split4(v, hi, lo, 0);
+        char* u = reinterpret_cast<char*>(a.out + (int64_t)grow * a.ldo + gcol) + 8 * q;
+        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+        *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+      } else {
+        float* o = a.out + (int64_t)grow * a.ldo + col;
+        if (nvalid == 4 && a.vec_ok) {
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+          for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+        }
+      }
+    }
   }
 }
 
@@ -362,107 +480,399 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 
   // ---- epilogue: accumulators -> LDS tile -> float4 rows ------------------------------------
   // (every wave passed the loop's final barrier, so the staging buffers are free)
+  acc_to_lds<TM, TN, LDC>(acc, sC, wm * (BM / WM), wn * (BN / WN), r, half);
+  __syncthreads();
+  epilogue_rows<BN, NT>(a, sC, m0, n0, t);
+}
+
+// ---- LDS-DMA variant (split-row sources, 128 x BN tile) ------------------------------------------
+// The staging path of the kernel above (buffer_load -> VGPR -> ds_write_b128) costs the LDS store
+// path 13 cycles per wave-instruction and 64 cache lines per load instruction (one row per lane).
+// Here every K step of a row is one 128-byte line of the split-row source - four 8-channel units,
+// each 16 B of hi halves then 16 B of lo halves - and one `buffer_load_dwordx4 ... lds` moves eight
+// rows x 128 B (eight full lines) straight into LDS: no staging registers, no ds_write, 1/8 of the
+// lines per instruction.  The LDS image is row-major, 128 B per row, and since an LDS-DMA writes lane l
+// at base + 16*l, the bank swizzle is applied on the SOURCE side: the lane that fills slot (row r,
+// 16-byte piece s) fetches piece s ^ ((r >> 1) & 7) of that row.  A fragment read of 32 consecutive
+// rows at one logical piece is then conflict-free for ds_read_b128's four 16-lane groups.
+// The weight operand uses the same image: piece 2u is unit u of the hi plane, 2u+1 of the lo plane
+// (both planes lie in one descriptor window).
+// Two LDS stages; the DMAs of step k+1 are issued right after the barrier that opens step k and are
+// waited for (vmcnt(0)) before the next one, so they have a whole step of MFMAs to land.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, char* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff_bytes, 0, 0, 0);
+#endif
+}
+
+// Waves WM x WN, each 32*TM x 32*TN outputs; 4 waves run two workgroups per CU, 8 waves one.
+// The grid is persistent: a workgroup walks tiles start + lw, start + lw + nl, ... of its XCD's
+// contiguous share of the tile space, and issues the first K step of the next tile in the slot where
+// the last step of the current one has nothing left to prefetch - the next tile's first loads are
+// in flight during the epilogue (which matters when K is short: the correlation GEMM has 8 steps).
+// PERSIST (plain wide f32 outputs = the correlation GEMMs): persistent grid, accumulators stored
+// straight to global, the next tile's first loads and this tile's stores overlap the neighbours' MFMAs.
+template <int TM, int TN, int WM, int WN, bool PERSIST>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
+  constexpr int AP = TBM / (8 * NW), BP = TBN / (8 * NW);  // 1-KiB pieces (8 rows x 128 B) per wave per K step
+  static_assert(TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0, "tile rows must split into whole pieces per wave");
+  constexpr int ASZ = TBM * 128, BSZ = TBN * 128, STG = ASZ + BSZ;
+  constexpr int LDC = TBN + 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sC = reinterpret_cast<float*>(smem_raw);
+
+  // this workgroup's tiles (XCD x = blockIdx & 7 owns a contiguous share of the tile space)
+  const int total = a.mtiles * a.ntiles;
+  int tile, tile_end, tile_step;
+  {
+    const int G = gridDim.x, xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    tile_step = (G - xcd + 7) >> 3;
+    tile = start + lw;
+    tile_end = start + q + (xcd < r ? 1 : 0);
+  }
+  if (tile >= tile_end) return;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // loader: piece j of this wave covers tile rows 8*NW*j + 8*wave .. +7; lane -> (row lane>>3, slot lane&7)
+  const int lrow = 8 * wave + (lane >> 3);
+  const int piece = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);   // slot ^ ((row >> 1) & 7)
+  const int kg = piece >> 1, hl = piece & 1;
+
+  int rp0[AP], rp1[AP];              // byte offsets of the row's first tap in source 0 / 1
+  unsigned long long tapok[AP];
+  int colbase[BP];
+  int kc, kky, kkx;   // channel within the tap and tap position of k = k0 + 8*kg, advanced by BK per step
+  int m0, n0;
+  auto setup = [&](int tl) {
+    int nt, mt;
+    if (a.ntiles >= 8) {
+      // wide outputs (GEMMs): the 64 tiles an XCD has in flight form an 8 x 8 block, so every operand
+      // tile it pulls into its L2 serves 8 workgroups (n-fastest order streams the whole second operand
+      // once per row tile, with no reuse when it exceeds the 4 MiB L2)
+      constexpr int GM = 8;
+      const int gsz = GM * a.ntiles;
+      const int g = tl / gsz, rem = tl - g * gsz;
+      const int left = a.mtiles - g * GM;
+      const int mrows = left < GM ? left : GM;
+      nt = rem / mrows;
+      mt = g * GM + (rem - nt * mrows);
+    } else {
+      nt = tl % a.ntiles;
+      mt = tl / a.ntiles;
+    }
+    m0 = mt * TBM;
+    n0 = nt * TBN;
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < AP; ++j) {
+      const int m = m0 + 8 * NW * j + lrow;
+      tapok[j] = 0ull;
+      rp0[j] = rp1[j] = 0;
+      if (a.pointwise) {       // 1x1, stride 1, no padding: output pixel m IS input pixel m (GEMM rows)
+        if (m < a.M) {
+          tapok[j] = 1ull;
+          rp0[j] = (m * a.ld0 + a.d0off) * 4;
+          rp1[j] = (m * a.ld1 + a.d1off) * 4;
+        }
+      } else if (m < a.M) {
+        const int hw = a.ho * a.wo;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int oy = rem / a.wo;
+        const int ox = rem - oy * a.wo;
+        const int iy0 = oy * a.stride - a.pad_h, ix0 = ox * a.stride - a.pad_w;
+        const int pix = (n * a.H + iy0) * a.W + ix0;
+        rp0[j] = (pix * a.ld0 + a.d0off) * 4;
+        rp1[j] = (pix * a.ld1 + a.d1off) * 4;
+        for (int ky = 0; ky < a.kh; ++ky)
+          for (int kx = 0; kx < a.kw; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W)
+              tapok[j] |= 1ull << (ky * a.kw + kx);
+      }
+    }
+    {
+      const int k = kg * 8;
+      const int tap = k / a.ctot;
+      kc = k - tap * a.ctot;
+      kky = tap / a.kw;
+      kkx = tap - kky * a.kw;
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const int col = n0 + 8 * NW * j + lrow;
+      colbase[j] = col < a.cout ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : 0x40000000;
+    }
+  };
+
+#ifdef VFML_EXPERIMENT_ZERODESC   // timing only: every DMA is range-checked away, the instruction stream stays
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, 0, 0x00020000);
+#else
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, a.bytes0, 0x00020000);
+#endif
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
+
+  auto load_step = [&](int stg, int k0) {
+#ifdef VFML_EXPERIMENT_NOLOAD
+    return;
+#endif
+    char* sa = smem_raw + stg * STG + wave * (8 * 128);
+    // channel-block order: this unit's channel can lie in the zero padding of the last block;
+    // tap order: the K tail of the last step
+    const bool kok = a.korder ? kc < a.ctot : k0 + kg * 8 < a.K;
+    int c = kc;
+    const bool s1 = c >= a.c0;
+    const int ld = s1 ? a.ld1 : a.ld0;
+    if (s1) c -= a.c0;
+    const int tapoff = ((kky * a.W + kkx) * ld + c) * 4 + hl * 16;
+    const int tap = kok ? kky * a.kw + kkx : 63;   // bit 63 is never set (kh*kw < 64, host check)
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const bool ok = (tapok[j] >> tap) & 1ull;
+      dma16(r0, ok ? (s1 ? rp1[j] : rp0[j]) + tapoff : OOB, sa + j * (8 * NW * 128));
+    }
+    if (a.korder) {          // next tap of the same 32 channels; after the last tap the next 32 channels
+      if (++kkx == a.kw) {
+        kkx = 0;
+        if (++kky == a.kh) {
+          kky = 0;
+          kc += BK;
+        }
+      }
+    } else {                 // next 32 channels of the same tap; after the last channel the next tap
+      int cn = kc + BK;
+      if (cn >= a.ctot) {
+        cn -= a.ctot;
+        if (++kkx == a.kw) {
+          kkx = 0;
+          ++kky;
+        }
+      }
+      kc = cn;
+    }
+    char* sb = smem_raw + stg * STG + ASZ + wave * (8 * 128);
+#pragma unroll
+    for (int j = 0; j < BP; ++j) dma16(rb, colbase[j] + k0 * 2, sb + j * (8 * NW * 128));
+  };
+
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+  const int r = lane & 31;
+  const int half = lane >> 5;
+  // fragment address of logical piece x at row r: row*128 + ((x ^ ((r>>1)&7)) * 16); x = 4*ks + 2*half + hl
+  const int q16 = ((((r >> 1) & 7) ^ (2 * half)) * 16);
+  const int aoff = (wm * (32 * TM) + r) * 128 + q16;
+  const int boff = ASZ + (wn * (32 * TN) + r) * 128 + q16;
+
+  f32x16 acc[TM][TN];
+
+  auto compute = [&](int stg) {
+    const char* base = smem_raw + stg * STG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64)) + i * 4096);
+        al[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64 + 16)) + i * 4096);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const h16x8*>(base + (boff ^ (ks * 64)) + j * 4096);
+        bl[j] = *reinterpret_cast<const h16x8*>(base + (boff ^ (ks * 64 + 16)) + j * 4096);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  // The step count is rounded up to even (one all-zero step when odd: out of range on the source side,
+  // the weight side reads the next row's first step - multiplied by zeros).
+  const int nk = (a.Kp / BK + 1) & ~1;
+  constexpr int NSTORE = TM * TN * 4;                    // direct epilogue: 16-byte stores per thread, all issued
+  constexpr int RELAXED = NSTORE < 63 ? NSTORE : 63;     // vmcnt that still covers the older DMAs
+  bool stores_behind = false;   // PERSIST: the previous tile's stores are still in flight behind this tile's first DMAs
+  auto step_pair = [&](int kt, bool last, int next) {
+    // A tile's first wait must not drain the previous tile's stores: vmcnt counts in issue order and the
+    // first step's DMAs were issued BEFORE them, so leaving min(63, NSTORE) operations outstanding still
+    // waits for every DMA (the stores then have one whole K step to finish before the next vmcnt(0)).
+    if (PERSIST && stores_behind) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAXED) : "memory");
+      stores_behind = false;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                       // stage 0 landed for every wave; stage 1's readers are done
+    load_step(1, (kt + 1) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!last) {
+      load_step(0, (kt + 2) * BK);
+    } else if (PERSIST && next < tile_end) {
+      setup(next);                         // the next tile's first step flies during this tile's epilogue
+      load_step(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  setup(tile);
+  load_step(0, 0);
+  while (true) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int col = wn * (BN / WN) + j * 32 + r;
-        sC[row * LDC + col] = acc[i][j][e];
-      }
-  __syncthreads();
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int cur_m0 = m0, cur_n0 = n0;
+    const int next = PERSIST ? tile + tile_step : tile_end;
+    // (direct epilogue) this tile's bias quad, loaded before the K loop: a load in the epilogue would make its
+    // s_waitcnt drain the previous tile's stores as well
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (PERSIST && a.bias) {
+      const int bc = cur_n0 + wn * (32 * TN) + (lane % (8 * TN)) * 4;
+      if (bc < a.cout) bv = *reinterpret_cast<const f32x4*>(a.bias + bc);
+    }
+#ifdef VFML_EXPERIMENT_STOREONLY   // timing only: epilogue without the K loop
+    if (PERSIST && next < tile_end) setup(next);
+#else
+    for (int kt = 0; kt < nk - 2; kt += 2) step_pair(kt, false, next);
+    step_pair(nk - 2, true, next);
+#endif
 
-  // 8 channels (one split-row unit) per thread, as two quads
-  constexpr int C8 = BN / 8;
-  constexpr int RPP = NT / C8;       // rows per pass
-  const int c8 = t % C8;
-  const int gcol = n0 + c8 * 8;
-  if (gcol >= a.cout) return;
-  const int epi = a.epilogue;
-  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if (a.bias) {
+#ifdef VFML_EXPERIMENT_NOSTORE   // timing only: no epilogue at all (accumulators kept alive)
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (gcol + e < a.cout) bias4[e >> 2][e & 3] = a.bias[gcol + e];
-  }
-  // reads 4 channels at (row, col) of an aux operand in either format
-  auto aux4 = [&](const float* base, int ld, int64_t row, int col) -> f32x4 {
-    f32x4 x;
-    if (a.aux16) {
-      const char* u = reinterpret_cast<const char*>(base + row * ld + (col & ~7)) + (col & 4) * 2;
-      const h16x2 h0 = *reinterpret_cast<const h16x2*>(u), h1 = *reinterpret_cast<const h16x2*>(u + 4);
-      const h16x2 l0 = *reinterpret_cast<const h16x2*>(u + 16), l1 = *reinterpret_cast<const h16x2*>(u + 20);
-      x[0] = (float)h0[0] + (float)l0[0];
-      x[1] = (float)h0[1] + (float)l0[1];
-      x[2] = (float)h1[0] + (float)l1[0];
-      x[3] = (float)h1[1] + (float)l1[1];
-    } else if (a.vec_ok) {
-      x = *reinterpret_cast<const f32x4*>(base + row * ld + col);
-    } else {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = base[row * ld + col + e];
-    }
-    return x;
-  };
-  for (int row = t / C8; row < BM; row += RPP) {
-    const int grow = m0 + row;
-    if (grow >= a.M) break;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int col = gcol + 4 * q;
-      if (col >= a.cout) break;
-      const bool lowhalf = col < a.split;   // split is a multiple of 4: a quad never straddles it
-      const int nvalid = a.cout - col >= 4 ? 4 : a.cout - col;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4 * q]);
-      f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
-      if (a.addend) {
-        if (nvalid == 4 && a.vec_ok) {
-          add4 = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + col);
-        } else {
-          for (int e = 0; e < nvalid; ++e) add4[e] = a.addend[(int64_t)grow * a.ld_addend + col + e];
-        }
+      for (int j = 0; j < TN; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(acc[i][j]));
+#endif
       }
+    if (true) {
+    } else
+#endif
+    if (PERSIST) {
+      // Wide plain-f32 outputs (the correlation GEMM: K is short, the tile's 4 bytes per product dominate).
+      // Each wave transposes its own 32*TM x 32*TN block through a private 32 x 32*TN slab in stage 1
+      // (stage 0 is already receiving the next tile) and writes whole rows of it as 16-byte stores: an
+      // instruction covers 64/(8*TN) rows x 128*TN contiguous bytes.  (Dword stores straight from the
+      // accumulators reach 2.4 TB/s, a third of what the chip writes with 16 bytes per lane.)
+      // Buffer stores through a per-tile descriptor: rows past M fall outside it, lanes past cout get an
+      // out-of-range offset, so every store instruction is issued (the relaxed vmcnt counts on NSTORE).
+      const int rows_valid = a.M - cur_m0 < TBM ? a.M - cur_m0 : TBM;
+      const int cols_valid = a.cout - cur_n0 < TBN ? a.cout - cur_n0 : TBN;
+      float* tbase = a.out + (int64_t)cur_m0 * a.ldo + cur_n0;
+      const __amdgpu_buffer_rsrc_t ro =
+          __builtin_amdgcn_make_buffer_rsrc(tbase, 0, ((rows_valid - 1) * a.ldo + cols_valid) * 4, 0x00020000);
+      constexpr int WC = 32 * TN;            // slab row, floats
+      constexpr int L4 = WC / 4;             // lanes per slab row
+      constexpr int RPI = 64 / L4;           // rows per store instruction
+      float* ws = reinterpret_cast<float*>(smem_raw + STG) + wave * (32 * WC);
+      const int c4 = (lane % L4) * 4, rr = lane / L4;
+      const int gcol = wn * WC + c4;                                   // column within the tile
+      const int lbase = gcol < cols_valid ? ((wm * (32 * TM) + rr) * a.ldo + gcol) * 4 : OOB;
+      __syncthreads();                       // every wave is done reading stage 1
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + add4[e] + bias4[q][e]) * a.out_scale;
-      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-      if (nvalid == 4) {
-        if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0 = aux4(a.aux0, a.ld_aux0, grow, col - a.split);
-        if (epi == VFML_EPI_GRU_Q) {
-          x0 = aux4(a.aux0, a.ld_aux0, grow, col);
-          x1 = aux4(a.aux1, a.ld_aux1, grow, col);
-        }
-        if (epi == VFML_EPI_ADD_AUX) x0 = aux4(a.aux0, a.ld_aux0, grow, col);
-      } else {
-        for (int e = 0; e < nvalid; ++e) {   // ragged tail: f32 operands only (host check)
-          if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e - a.split];
-          if (epi == VFML_EPI_GRU_Q) {
-            x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
-            x1[e] = a.aux1[(int64_t)grow * a.ld_aux1 + col + e];
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ws[((e & 3) + 8 * (e >> 2) + 4 * half) * WC + j * 32 + r] = acc[i][j][e];
+        // (same wave, LDS operations complete in order: no barrier between the writes and the reads)
+#pragma unroll
+        for (int p = 0; p < 32 / RPI; ++p) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(ws + (p * RPI + rr) * WC + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = (v[e] * a.w_inv + bv[e]) * a.out_scale;   // same expression as epilogue_rows
+            if (a.epilogue == VFML_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
           }
-          if (epi == VFML_EPI_ADD_AUX) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
+          const int roff = (i * 32 + p * RPI) * a.ldo * 4;
+#ifndef VFML_STORE_AUX
+#define VFML_STORE_AUX 2      // nt: the volume is streamed out once
+#endif
+#ifdef VFML_EXPERIMENT_GLOBALSTORE
+          if (gcol < cols_valid && wm * (32 * TM) + rr + i * 32 + p * RPI < rows_valid)
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tbase) + lbase + roff) = v;
+#else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, gcol < cols_valid ? lbase + roff : OOB, 0,
+                                                 VFML_STORE_AUX);
+#endif
         }
       }
+      stores_behind = true;
+    } else {
+      // Epilogue in TM slabs: slab i holds block row i of every wave (WM*32 rows x TBN) in LDS.
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = epi1(v[e], epi, lowhalf, x0[e], x1[e]);
-      if (a.out16) {
-        // hi quad at unit + 8q bytes, lo quad at unit + 16 + 8q (cout % 4 == 0, host check)
-        U8 hi, lo;
-        split4(v, hi, lo, 0);
-        char* u = reinterpret_cast<char*>(a.out + (int64_t)grow * a.ldo + gcol) + 8 * q;
-        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
-        *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
-      } else {
-        float* o = a.out + (int64_t)grow * a.ldo + col;
-        if (nvalid == 4 && a.vec_ok) {
-          *reinterpret_cast<f32x4*>(o) = v;
-        } else {
-          for (int e = 0; e < nvalid; ++e) o[e] = v[e];
-        }
+      for (int i = 0; i < TM; ++i) {
+        __syncthreads();     // every wave is done with the stage buffers / with the previous slab
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int col = wn * (32 * TN) + j * 32 + r;
+            sC[row * LDC + col] = acc[i][j][e];
+          }
+        __syncthreads();
+        epilogue_rows<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
       }
     }
+    if (!PERSIST || next >= tile_end) break;
+    tile = next;
   }
+}
+
+template <int TM, int TN, int WM, int WN, bool PERSIST>
+int launch_dma_k(SplitArgs& a, hipStream_t s) {
+  constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
+  constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
+  constexpr size_t slab = (size_t)WM * 32 * (TBN + 4) * 4;
+  constexpr size_t lds = (PERSIST || stage > slab) ? stage : slab;
+  static_assert(lds <= 160 * 1024, "LDS");
+  a.mtiles = (a.M + TBM - 1) / TBM;
+  a.ntiles = (a.cout + TBN - 1) / TBN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_done = true;
+  }
+  // PERSIST: one workgroup per resident slot (256 CUs x 2 or 1), fewer when there are fewer tiles
+  const int64_t total = (int64_t)a.mtiles * a.ntiles;
+  const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
+  const int grid = (int)(PERSIST && total > slots ? slots : total);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  return vfml_check_launch("vfml_conv2d_split");
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_dma(SplitArgs& a, hipStream_t s) {
+  if (a.direct) return launch_dma_k<2, 2, 2, 2, true>(a, s);   // (the one persistent tile shape that does not spill)
+  return launch_dma_k<TM, TN, WM, WN, false>(a, s);
 }
 
 template <int BN, int WM, int WN, bool BIGC, bool IN16>
@@ -625,8 +1035,10 @@ extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, flo
 }
 
 extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
-                                 int in_fmt, int out_fmt, int aux_fmt, void* stream) {
+                                 int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
+  VFML_REQUIRE(k_order == VFML_KORDER_TAP || (k_order == VFML_KORDER_CBLOCK && in_fmt == VFML_FMT_S16),
+               "vfml_conv2d_split: bad k_order (channel-block order needs split-row sources)");
   VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
                (aux_fmt == VFML_FMT_F32 || aux_fmt == VFML_FMT_S16), "vfml_conv2d_split: bad format selector");
   const bool in16 = in_fmt == VFML_FMT_S16;
@@ -655,7 +1067,11 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                "vfml_conv2d_split: in0/in1/w_hi/w_lo must be 16-byte aligned");
   VFML_REQUIRE(w_scale > 0.f, "vfml_conv2d_split: w_scale must be the positive scale given to vfml_split_f16");
   const int K = d->kh * d->kw * (d->c0 + d->c1);
-  VFML_REQUIRE(kp >= K && kp % BK == 0 && kp < K + BK, "vfml_conv2d_split: kp=%d must be K=%d rounded up to %d", kp, K, BK);
+  if (k_order == VFML_KORDER_CBLOCK)
+    VFML_REQUIRE(kp == d->kh * d->kw * ((d->c0 + d->c1 + BK - 1) / BK * BK),
+                 "vfml_conv2d_split: kp=%d must be kh*kw*roundup32(c0+c1) in channel-block order", kp);
+  else
+    VFML_REQUIRE(kp >= K && kp % BK == 0 && kp < K + BK, "vfml_conv2d_split: kp=%d must be K=%d rounded up to %d", kp, K, BK);
   const int ho = (d->h + 2 * d->pad_h - d->kh) / d->stride + 1;
   const int wo = (d->w + 2 * d->pad_w - d->kw) / d->stride + 1;
   VFML_REQUIRE(ho > 0 && wo > 0, "vfml_conv2d_split: empty output");
@@ -676,6 +1092,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_ADD_AUX, "vfml_conv2d_split: bad epilogue");
 
   SplitArgs a;
+  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0;
+  a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;
   const int64_t e0 = (d->in0 - base) + ((int64_t)d->n * d->h * d->w - 1) * d->ld0 + d->c0;
@@ -721,6 +1139,48 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
     if (force == 64 || (force == 0 && eff(64) > eff(128))) bn = 64;
   }
   if (in16) {   // split-row sources: every slice is a multiple of 8 channels and >= one K step wide
+    // LDS-DMA kernel when both weight planes fit one descriptor window (< 1 GiB)
+    static const int no_dma = getenv("VFML_NO_DMA") ? atoi(getenv("VFML_NO_DMA")) : 0;
+    const char* ph = (const char*)w_hi;
+    const char* pl = (const char*)w_lo;
+    const char* wb = ph < pl ? ph : pl;
+    const int64_t ext = (ph < pl ? pl - ph : ph - pl) + (int64_t)d->cout * kp * 2;
+    const bool dma_ok = ext < (1ll << 30);
+    VFML_REQUIRE(k_order == VFML_KORDER_TAP || dma_ok,
+                 "vfml_conv2d_split: channel-block order needs w_hi and w_lo within 1 GiB of each other");
+    if (dma_ok && (k_order == VFML_KORDER_CBLOCK || (!no_dma && bn == 128))) {
+      a.wbase = wb; a.whi_off = (int)(ph - wb); a.wlo_off = (int)(pl - wb); a.bytesb = (int)ext;
+      static const int direct_min = getenv("VFML_DIRECT_MIN") ? atoi(getenv("VFML_DIRECT_MIN")) : 1024;
+      a.direct = (d->epilogue == VFML_EPI_NONE || d->epilogue == VFML_EPI_RELU) && !d->addend && out_fmt == VFML_FMT_F32 &&
+                 d->cout >= direct_min && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&
+                 (!d->bias || vfml_aligned16(d->bias));
+      static const char* tile_env = getenv("VFML_DMA_TILE");   // experiments: "TM,TN,WM,WN"
+      int cfg = d->cout > 32 ? 2122 : 1141;
+      if (d->cout > 64) {
+        // 192 x 128, 128 x 192 or 128 x 128 (two workgroups per CU each): least padded MFMA work; the
+        // 128 x 128 tile moves 17 % more operand bytes per MFMA (measured ~7 % slower at equal work)
+        const int64_t m128 = (a.M + 127) / 128, m192 = (a.M + 191) / 192;
+        const int64_t n128 = (d->cout + 127) / 128, n192 = (d->cout + 191) / 192;
+        const double c3222 = (double)(m192 * n128) * 6.0, c2322 = (double)(m128 * n192) * 6.0,
+                     c2222 = (double)(m128 * n128) * 4.0 / 0.93;
+        cfg = c3222 <= c2322 && c3222 <= c2222 ? 3222 : (c2322 <= c2222 ? 2322 : 2222);
+      }
+      if (tile_env && d->cout > 64) {
+        int tm = 2, tn = 2, wm = 2, wn = 2;
+        sscanf(tile_env, "%d,%d,%d,%d", &tm, &tn, &wm, &wn);
+        cfg = tm * 1000 + tn * 100 + wm * 10 + wn;
+      }
+      switch (cfg) {
+        case 3222: return launch_dma<3, 2, 2, 2>(a, s);   // 192 x 128, 2 workgroups per CU
+        case 2322: return launch_dma<2, 3, 2, 2>(a, s);   // 128 x 192
+        case 2242: return launch_dma<2, 2, 4, 2>(a, s);   // 256 x 128, 8 waves
+        case 3224: return launch_dma<3, 2, 2, 4>(a, s);   // 192 x 256, 8 waves
+        case 4224: return launch_dma<4, 2, 2, 4>(a, s);   // 256 x 256, 8 waves
+        case 2122: return launch_dma<2, 1, 2, 2>(a, s);   // 128 x 64
+        case 1141: return launch_dma<1, 1, 4, 1>(a, s);   // 128 x 32
+        default: return launch_dma<2, 2, 2, 2>(a, s);
+      }
+    }
     if (bn == 128) {
       a.ntiles = (d->cout + 127) / 128;
       return launch<128, 2, 2, true, true>(a, s);

@@ -18,6 +18,7 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "
 
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
+KORDER_TAP, KORDER_CBLOCK = 0, 1   # K-axis order of split weight planes (include/vfml.h)
 
 
 class ConvDesc(ctypes.Structure):
@@ -68,7 +69,8 @@ def lib():
     L.vfml_last_error.restype = c_char_p
     L.vfml_abi_version.restype = c_int
     L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
-    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
+    L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int,
+                                    c_void_p]
     L.vfml_to_s16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_softmax_rows_s16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_void_p]
     L.vfml_transpose_split_f16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
@@ -88,7 +90,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 6:
+    if L.vfml_abi_version() != 7:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -150,12 +152,25 @@ def profile_end():
     return out
 
 
-def conv_variant(cout, split=False, ctot=32, in16=False):
-    """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (the
-    split kernel's rare 64-wide choice for cout > 64 is not modelled here)."""
+def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False):
+    """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
+    the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
+    split kernel for cout > 64 is not modelled)."""
     tile = "128, 2, 2" if cout > 64 else ("64, 2, 2" if cout > 32 else "32, 4, 1")
     if not split:
         return f"conv_gemm_kernel<{tile}>"
+    dma = in16 and (order == KORDER_CBLOCK or (cout > 64 and not os.environ.get("VFML_NO_DMA")))
+    if dma:     # split-f16, LDS-DMA staged
+        if plain_f32_out and cout >= 1024 and cout % 4 == 0:
+            return "conv_gemm_dma_kernel<2, 2, 2, 2, true>"          # persistent GEMM form
+        if cout <= 32:
+            return "conv_gemm_dma_kernel<1, 1, 4, 1, false>"
+        if cout <= 64:
+            return "conv_gemm_dma_kernel<2, 1, 2, 2, false>"
+        m128, m192, n128, n192 = -(-m // 128), -(-m // 192), -(-cout // 128), -(-cout // 192)
+        c3222, c2322, c2222 = m192 * n128 * 6.0, m128 * n192 * 6.0, m128 * n128 * 4.0 / 0.93
+        t = "3, 2, 2, 2" if (c3222 <= c2322 and c3222 <= c2222) else ("2, 3, 2, 2" if c2322 <= c2222 else "2, 2, 2, 2")
+        return f"conv_gemm_dma_kernel<{t}, false>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
 
@@ -167,8 +182,10 @@ class SplitWeight:
     def __init__(self, rows, k, device):
         self.rows, self.k, self.kp = rows, k, (k + 31) // 32 * 32
         self.scale = 1.0
-        self.hi = torch.empty(rows * self.kp, dtype=torch.float16, device=device)
-        self.lo = torch.empty(rows * self.kp, dtype=torch.float16, device=device)
+        self.order = KORDER_TAP     # set to KORDER_CBLOCK by whoever fills it with pack_conv_weight(cblock=True)
+        # one allocation: the LDS-DMA conv kernel reaches both planes through one buffer descriptor
+        self.planes = torch.empty(2 * rows * self.kp, dtype=torch.float16, device=device)
+        self.hi, self.lo = self.planes[:rows * self.kp], self.planes[rows * self.kp:]
 
     @staticmethod
     def auto_scale(absmax):
@@ -219,7 +236,8 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         def launch():
             _check(lib().vfml_conv2d_split(ctypes.byref(d), c_void_p(weight.hi.data_ptr() + 2 * weight_off * weight.kp),
                                            c_void_p(weight.lo.data_ptr() + 2 * weight_off * weight.kp), weight.kp,
-                                           weight.scale, in_fmt, out_fmt, aux_fmt, _stream()), "vfml_conv2d_split")
+                                           weight.scale, in_fmt, out_fmt, aux_fmt, weight.order, _stream()),
+                   "vfml_conv2d_split")
     else:
         if in_fmt != FMT_F32 or out_fmt != FMT_F32 or aux_fmt != FMT_F32:
             raise ValueError("the exact-f32 kernel (vfml_conv2d) takes and writes plain f32 activations only")
@@ -235,7 +253,10 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     e0.record()
     launch()
     e1.record()
-    _PROFILE.append((conv_variant(cout, is_split, c0 + c1, in_fmt == FMT_S16), 2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
+    plain = (epilogue in (EPI_NONE, EPI_RELU) and addend is None and out_fmt == FMT_F32 and ldo % 4 == 0)
+    _PROFILE.append((conv_variant(cout, is_split, c0 + c1, in_fmt == FMT_S16, n * ho * wo,
+                                  weight.order if is_split else KORDER_TAP, plain),
+                     2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):

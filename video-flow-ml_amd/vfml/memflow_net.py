@@ -84,7 +84,7 @@ class MemFlowNetHIP(MOFNetHIP):
                tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        P, hid = {}, self.hidden_dim
+        P, hid, cblock_names = {}, self.hidden_dim, set()
         ub = "update_block"
         for name, cout, cin, kh, kw in self._spec:
             leaf = self._param(name)
@@ -93,7 +93,11 @@ class MemFlowNetHIP(MOFNetHIP):
             if name.endswith(".encoder.convc1"):       # lookup block padded to whole units (zero weights)
                 cor_p = (cin + 7) // 8 * 8 if split else (cin + 3) // 4 * 4
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cor_p - cin))
-            P[name] = (pack_conv_weight(w, cin_pad=4 if cin in (2, 3) else None), b)
+            # update-block convolutions read split-row activations (all but convf1): channel-block K order
+            cb = split and name.startswith(ub + ".") and not name.endswith(".convf1")
+            if cb:
+                cblock_names.add(name)
+            P[name] = (pack_conv_weight(w, cin_pad=4 if cin in (2, 3) else None, cblock=cb), b)
         self._cout_of = {}
         for k in ("1", "2"):
             raw = {g: self._param(f"{ub}.gru.conv{g}{k}") for g in "zrq"}
@@ -103,8 +107,10 @@ class MemFlowNetHIP(MOFNetHIP):
             bq = raw["q"].bias.detach().to(device=device, dtype=torch.float32)
             for nm, wfull, bfull, co in ((f"{ub}.gru.convzr{k}", wzr, bzr, 2 * hid), (f"{ub}.gru.convq{k}", wq, bq, hid)):
                 it = torch.cat([wfull[:, :hid], wfull[:, 2 * hid:]], dim=1)
-                P[nm + ".iter"] = (pack_conv_weight(it), None)
-                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid]), bfull.contiguous())
+                P[nm + ".iter"] = (pack_conv_weight(it, cblock=split), None)
+                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid], cblock=split), bfull.contiguous())
+                if split:
+                    cblock_names.update((nm + ".iter", nm + ".ctx"))
                 self._cout_of[nm + ".iter"] = co
             for g in "zrq":
                 del P[f"{ub}.gru.conv{g}{k}"]
@@ -113,7 +119,9 @@ class MemFlowNetHIP(MOFNetHIP):
                 for name, (wflat, b) in list(P.items()):
                     cout = self._cout_of[name] if name in self._cout_of else b.numel()
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
-                    P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
+                    sw = hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc)
+                    sw.order = hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP
+                    P[name] = (sw, b)
         self._gamma = float(self._param(ub).gamma.item())   # read once per load: .item() synchronises
         self._packed, self._packed_key = P, key
         self._packed_serial += 1

@@ -85,7 +85,7 @@ class MOFNetHIP(_Holder):
                tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        P = {}
+        P, cblock_names = {}, set()
         for name, cout, cin, kh, kw in self._spec:
             leaf = self._param(name)
             w = leaf.weight.detach().to(device=device, dtype=torch.float32)
@@ -104,7 +104,12 @@ class MOFNetHIP(_Holder):
             if name.endswith(".tprop"):
                 # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
                 w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
-            P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None),
+            # update-block convolutions read split-row activations (all but convf1, whose input is the
+            # 4-channel f32 flow): their weights go in channel-block K order (include/vfml.h)
+            cb = split and name.startswith("update_block.") and not name.endswith(".convf1")
+            if cb:
+                cblock_names.add(name)
+            P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None, cblock=cb),
                        leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous())
         # GRU gates.  Input channels are [h | inp | motion | temporal]; `inp` (the context map) does not
         # change over the iterations, so its part of every gate convolution (+ bias) is computed once per
@@ -122,8 +127,10 @@ class MOFNetHIP(_Holder):
             bq = raw["q"].bias.detach().to(device=device, dtype=torch.float32)
             for nm, wfull, bfull in ((f"update_block.gru.convzr{k}", wzr, bzr), (f"update_block.gru.convq{k}", wq, bq)):
                 it = torch.cat([wfull[:, :hid], wfull[:, 2 * hid:]], dim=1)
-                P[nm + ".iter"] = (pack_conv_weight(it), None)
-                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid]), bfull.contiguous())
+                P[nm + ".iter"] = (pack_conv_weight(it, cblock=split), None)
+                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid], cblock=split), bfull.contiguous())
+                if split:
+                    cblock_names.update((nm + ".iter", nm + ".ctx"))
             for g in "zrq":
                 del P[f"update_block.gru.conv{g}{k}"]
         if split:
@@ -132,7 +139,9 @@ class MOFNetHIP(_Holder):
                 for name, (wflat, b) in list(P.items()):
                     cout = self._cout_of[name] if name in self._cout_of else b.numel()
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
-                    P[name] = (hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc), b)
+                    sw = hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc)
+                    sw.order = hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP
+                    P[name] = (sw, b)
         self._packed, self._packed_key = P, key
         self._packed_serial += 1          # new weights: cached encoder outputs are stale
         self._feat_cache.clear()

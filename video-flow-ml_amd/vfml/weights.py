@@ -103,9 +103,15 @@ def write_seeded_checkpoint(root, cfg, seed=0, architecture="mof", dataset="sint
     return path
 
 
-def pack_conv_weight(w, cin_pad=None):
-    """[cout, cin, kh, kw] -> flat [cout][kh][kw][cin(+pad)] float32 (the kernels' K order)."""
+def pack_conv_weight(w, cin_pad=None, cblock=False):
+    """[cout, cin, kh, kw] -> flat [cout][kh][kw][cin(+pad)] float32 (the kernels' K order), or with
+    `cblock` the channel-block order [cout][cin/32][kh][kw][32] (cin zero padded to a multiple of 32;
+    include/vfml.h VFML_KORDER_CBLOCK)."""
     cout, cin, kh, kw = w.shape
+    if cblock:
+        cp = (cin + 31) // 32 * 32
+        w = torch.nn.functional.pad(w.detach().to(torch.float32), (0, 0, 0, 0, 0, cp - cin))
+        return w.reshape(cout, cp // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).contiguous().reshape(-1)
     w = w.detach().to(torch.float32).permute(0, 2, 3, 1)
     if cin_pad is not None and cin_pad > cin:
         w = torch.nn.functional.pad(w, (0, cin_pad - cin))
