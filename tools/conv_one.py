@@ -8,7 +8,10 @@ n, h, w, cin, cout, kh, kw = 3, 135, 240, 512, 256, 1, 5
 x = torch.randn(n * h * w * cin, device="cuda")
 wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
 b = torch.randn(cout, device="cuda")
-wobj = hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
+from vfml.weights import pack_conv_weight
+wc = pack_conv_weight(wt.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2), cblock=True)
+wobj = hip.SplitWeight(cout, wc.numel() // cout, x.device).fill(wc, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
+wobj.order = hip.KORDER_CBLOCK
 out = torch.empty(n * h * w * cout, device="cuda")
 fmt = hip.FMT_S16 if os.environ.get("S16", "1") == "1" else hip.FMT_F32
 if fmt == hip.FMT_S16:

@@ -619,11 +619,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #endif
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
 
-  auto load_step = [&](int stg, int k0) {
-#ifdef VFML_EXPERIMENT_NOLOAD
-    return;
-#endif
-    char* sa = smem_raw + stg * STG + wave * (8 * 128);
+  // The loads of a K step: offsets first (prep_step, VALU), then one LDS-DMA instruction per piece
+  // (issue_piece), which the step loop places BETWEEN the MFMA groups of the step before - a wave issues in
+  // order, and a piece takes ~100 cycles to get through the texture path when the CU is filling LDS
+  // at its rate; issued in a block ahead of the MFMAs, the pieces of a step hold the wave's matrix pipe idle.
+  int va[AP], vb[BP];
+  auto prep_step = [&](int k0) {
     // channel-block order: this unit's channel can lie in the zero padding of the last block;
     // tap order: the K tail of the last step
     const bool kok = a.korder ? kc < a.ctot : k0 + kg * 8 < a.K;
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       const bool ok = (tapok[j] >> tap) & 1ull;
-      dma16(r0, ok ? (s1 ? rp1[j] : rp0[j]) + tapoff : OOB, sa + j * (8 * NW * 128));
+      va[j] = ok ? (s1 ? rp1[j] : rp0[j]) + tapoff : OOB;
     }
     if (a.korder) {          // next tap of the same 32 channels; after the last tap the next 32 channels
       if (++kkx == a.kw) {
@@ -657,9 +658,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       }
       kc = cn;
     }
-    char* sb = smem_raw + stg * STG + ASZ + wave * (8 * 128);
 #pragma unroll
-    for (int j = 0; j < BP; ++j) dma16(rb, colbase[j] + k0 * 2, sb + j * (8 * NW * 128));
+    for (int j = 0; j < BP; ++j) vb[j] = colbase[j] + k0 * 2;
+  };
+  auto issue_piece = [&](int stg, int pc) {
+#ifdef VFML_EXPERIMENT_NOLOAD
+    return;
+#endif
+    if (pc < AP)
+      dma16(r0, va[pc < AP ? pc : 0], smem_raw + stg * STG + wave * (8 * 128) + pc * (8 * NW * 128));
+    else if (pc < AP + BP)
+      dma16(rb, vb[pc >= AP && pc < AP + BP ? pc - AP : 0], smem_raw + stg * STG + ASZ + wave * (8 * 128) + (pc - AP) * (8 * NW * 128));
+  };
+  auto issue_all = [&](int stg) {
+#pragma unroll
+    for (int pc = 0; pc < AP + BP; ++pc) issue_piece(stg, pc);
   };
 
   const int wm = wave / WN;
@@ -673,7 +686,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 
   f32x16 acc[TM][TN];
 
-  auto compute = [&](int stg) {
+  // MFMAs of the step in stage `stg`; after each (i, j) group of three, one piece of the step that
+  // prep_step prepared goes out to stage `lstg` (when `issue`)
+  auto compute = [&](int stg, int lstg, bool issue) {
     const char* base = smem_raw + stg * STG;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -695,6 +710,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          constexpr int GROUPS = 2 * TM * TN;
+          const int g = (ks * TM + i) * TN + j;
+          // spread AP+BP pieces over the GROUPS groups (the first groups get one more when it does not divide)
+          constexpr int PER = (AP + BP + GROUPS - 1) / GROUPS;
+          if (issue) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) issue_piece(lstg, g * PER + q);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
   };
@@ -716,25 +740,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();                       // stage 0 landed for every wave; stage 1's readers are done
-    load_step(1, (kt + 1) * BK);
+    prep_step((kt + 1) * BK);
     __builtin_amdgcn_sched_barrier(0);
-    compute(0);
-    __builtin_amdgcn_sched_barrier(0);
+    compute(0, 1, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bool issue = true;
     if (!last) {
-      load_step(0, (kt + 2) * BK);
+      prep_step((kt + 2) * BK);
     } else if (PERSIST && next < tile_end) {
       setup(next);                         // the next tile's first step flies during this tile's epilogue
-      load_step(0, 0);
+      prep_step(0);
+    } else {
+      issue = false;
     }
     __builtin_amdgcn_sched_barrier(0);
-    compute(1);
-    __builtin_amdgcn_sched_barrier(0);
+    compute(1, 0, issue);
   };
 
   setup(tile);
-  load_step(0, 0);
+  prep_step(0);
+  issue_all(0);
   while (true) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -751,12 +777,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       const int bc = cur_n0 + wn * (32 * TN) + (lane % (8 * TN)) * 4;
       if (bc < a.cout) bv = *reinterpret_cast<const f32x4*>(a.bias + bc);
     }
-#ifdef VFML_EXPERIMENT_STOREONLY   // timing only: epilogue without the K loop
-    if (PERSIST && next < tile_end) setup(next);
-#else
     for (int kt = 0; kt < nk - 2; kt += 2) step_pair(kt, false, next);
     step_pair(nk - 2, true, next);
-#endif
 
 #ifdef VFML_EXPERIMENT_NOSTORE   // timing only: no epilogue at all (accumulators kept alive)
 #pragma unroll
@@ -810,13 +832,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #ifndef VFML_STORE_AUX
 #define VFML_STORE_AUX 2      // nt: the volume is streamed out once
 #endif
-#ifdef VFML_EXPERIMENT_GLOBALSTORE
-          if (gcol < cols_valid && wm * (32 * TM) + rr + i * 32 + p * RPI < rows_valid)
-            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(tbase) + lbase + roff) = v;
-#else
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, gcol < cols_valid ? lbase + roff : OOB, 0,
                                                  VFML_STORE_AUX);
-#endif
         }
       }
       stores_behind = true;
