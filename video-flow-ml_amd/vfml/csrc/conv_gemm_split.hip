@@ -1174,13 +1174,22 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
       static const char* tile_env = getenv("VFML_DMA_TILE");   // experiments: "TM,TN,WM,WN"
       int cfg = d->cout > 32 ? 2122 : 1141;
       if (d->cout > 64) {
-        // 192 x 128, 128 x 192 or 128 x 128 (two workgroups per CU each): least padded MFMA work; the
-        // 128 x 128 tile moves 17 % more operand bytes per MFMA (measured ~7 % slower at equal work)
-        const int64_t m128 = (a.M + 127) / 128, m192 = (a.M + 191) / 192;
-        const int64_t n128 = (d->cout + 127) / 128, n192 = (d->cout + 191) / 192;
-        const double c3222 = (double)(m192 * n128) * 6.0, c2322 = (double)(m128 * n192) * 6.0,
-                     c2222 = (double)(m128 * n128) * 4.0 / 0.93;
-        cfg = c3222 <= c2322 && c3222 <= c2222 ? 3222 : (c2322 <= c2222 ? 2322 : 2222);
+        // 192 x 128, 128 x 192, 128 x 128 or 128 x 64 tiles (two workgroups per CU each).  Cost model:
+        // (rounds over the 512 resident slots; a problem that does not fill them is one round, a longer one
+        // costs its fractional number of rounds because workgroups of the last round run less contended)
+        // x (MFMAs per tile / measured relative efficiency of the tile shape: fewer operand bytes per MFMA
+        // on the larger tiles).
+        auto cost = [&](int tbm, int tbn, double mf, double eff) {
+          const double tiles = (double)((a.M + tbm - 1) / tbm) * (double)((d->cout + tbn - 1) / tbn);
+          return (tiles > 512.0 ? tiles / 512.0 : 1.0) * mf / eff;
+        };
+        const double c3222 = cost(192, 128, 6.0, 1.0), c2322 = cost(128, 192, 6.0, 1.0), c2222 = cost(128, 128, 4.0, 0.93),
+                     c2122 = cost(128, 64, 2.0, 0.7);
+        cfg = 3222;
+        double best = c3222;
+        if (c2322 < best) { best = c2322; cfg = 2322; }
+        if (c2222 < best) { best = c2222; cfg = 2222; }
+        if (c2122 < best) { best = c2122; cfg = 2122; }
       }
       if (tile_env && d->cout > 64) {
         int tm = 2, tn = 2, wm = 2, wn = 2;

@@ -167,9 +167,16 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
             return "conv_gemm_dma_kernel<1, 1, 4, 1, false>"
         if cout <= 64:
             return "conv_gemm_dma_kernel<2, 1, 2, 2, false>"
-        m128, m192, n128, n192 = -(-m // 128), -(-m // 192), -(-cout // 128), -(-cout // 192)
-        c3222, c2322, c2222 = m192 * n128 * 6.0, m128 * n192 * 6.0, m128 * n128 * 4.0 / 0.93
-        t = "3, 2, 2, 2" if (c3222 <= c2322 and c3222 <= c2222) else ("2, 3, 2, 2" if c2322 <= c2222 else "2, 2, 2, 2")
+        def cost(tbm, tbn, mf, eff):
+            tiles = -(-m // tbm) * -(-cout // tbn)
+            return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
+        cands = [(cost(192, 128, 6.0, 1.0), "3, 2, 2, 2"), (cost(128, 192, 6.0, 1.0), "2, 3, 2, 2"),
+                 (cost(128, 128, 4.0, 0.93), "2, 2, 2, 2"), (cost(128, 64, 2.0, 0.7), "2, 1, 2, 2")]
+        t = cands[0][1]
+        best = cands[0][0]
+        for c, name in cands[1:]:
+            if c < best:
+                best, t = c, name
         return f"conv_gemm_dma_kernel<{t}, false>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
