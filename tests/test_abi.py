@@ -56,3 +56,56 @@ def test_conv_desc_layout_matches_header():
     want = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "int32_t": ctypes.c_int32,
             "float": ctypes.c_float}
     assert [(n, want[t]) for n, t in fields] == list(hip.ConvDesc._fields_)
+
+
+def _gfx950_code_objects(lib_path):
+    """Code objects of every translation unit in the library's .hip_fatbin section (clang offload bundles)."""
+    import struct
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib_path, os.path.join(tmp, "copy.so")], check=True)
+        blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], blob.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", blob, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tlen].decode()
+            q += 24 + tlen
+            if "gfx950" in triple:
+                out.append(blob[pos + off:pos + off + size])
+        pos = blob.find(magic, pos + len(magic))
+    return out
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every kernel of the library keeps its state in registers: private (scratch) segment size 0 and no
+    spilled VGPRs/SGPRs in the code-object metadata.  (hipcc silently moves accumulator arrays to scratch
+    when it stops unrolling an MFMA loop - a 40x slowdown that no numerics test notices.)"""
+    import re
+    import subprocess
+    import tempfile
+    from vfml import hip
+    hip.build()
+    cos = _gfx950_code_objects(hip.LIB_PATH)
+    assert len(cos) >= 4
+    seen = 0
+    for co in cos:
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], check=True,
+                                   capture_output=True, text=True).stdout
+        for name, body in re.findall(r"\.name:\s+(\S+)(.*?)(?=\n\s+- \.|\Z)", notes, flags=re.S):
+            vals = dict(re.findall(r"\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count):\s+(\d+)", body))
+            if "private_segment_fixed_size" not in vals:
+                continue
+            seen += 1
+            assert int(vals["private_segment_fixed_size"]) == 0, f"{name} uses {vals['private_segment_fixed_size']} B of scratch"
+            assert int(vals.get("vgpr_spill_count", 0)) == 0, f"{name} spills VGPRs"
+    assert seen >= 30      # conv / GEMM instantiations + the streaming kernels

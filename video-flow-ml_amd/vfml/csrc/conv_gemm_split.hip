@@ -70,6 +70,9 @@ struct SplitArgs {
   int korder;   // VFML_KORDER_*
   int direct;   // LDS-DMA kernel: plain f32 output written straight from the accumulators
   int pointwise;  // 1x1 / stride 1 / no padding
+  // uniform-step loader of the LDS-DMA kernel (channel-block order, whole 32-channel blocks per source,
+  // one row stride): per K step the tap / channel offset is one scalar
+  int fastk, abias, src1_delta;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -501,9 +504,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 // waited for (vmcnt(0)) before the next one, so they have a whole step of MFMAs to land.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, char* lds) {
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, char* lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff_bytes, 0, 0, 0);
+  // address = base + voffset + soffset; only voffset is range-checked (an out-of-range lane writes zeros)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff_bytes, soff_bytes, 0, 0);
 #endif
 }
 
@@ -514,7 +518,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 // in flight during the epilogue (which matters when K is short: the correlation GEMM has 8 steps).
 // PERSIST (plain wide f32 outputs = the correlation GEMMs): persistent grid, accumulators stored
 // straight to global, the next tile's first loads and this tile's stores overlap the neighbours' MFMAs.
-template <int TM, int TN, int WM, int WN, bool PERSIST>
+// FASTK: the uniform-step loader (SplitArgs::fastk) as a compile-time choice - with both loaders in one
+// body hipcc stops unrolling the MFMA loops of the larger tiles and the accumulators go to scratch.
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
@@ -551,6 +557,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   unsigned long long tapok[AP];
   int colbase[BP];
   int kc, kky, kkx;   // channel within the tap and tap position of k = k0 + 8*kg, advanced by BK per step
+  int scb = 0, sky = 0, skx = 0;   // uniform-step loader: channel block and tap of the step (scalars)
   int m0, n0;
   auto setup = [&](int tl) {
     int nt, mt;
@@ -605,6 +612,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       kky = tap / a.kw;
       kkx = tap - kky * a.kw;
     }
+    if (FASTK) {
+      // uniform-step loader: rp0 = row base + this lane's bytes within a 32-channel block, shifted by abias so
+      // that it is never negative (the descriptor base is shifted back); tapok holds the INVERTED tap mask
+#pragma unroll
+      for (int j = 0; j < AP; ++j) {
+        rp0[j] += a.abias + kg * 32 + hl * 16;
+        tapok[j] = ~tapok[j];
+      }
+      scb = sky = skx = 0;
+    }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int col = n0 + 8 * NW * j + lrow;
@@ -615,7 +632,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #ifdef VFML_EXPERIMENT_ZERODESC   // timing only: every DMA is range-checked away, the instruction stream stays
   const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, 0, 0x00020000);
 #else
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, a.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(const_cast<float*>(a.in0)) - a.abias, 0, a.bytes0 + a.abias, 0x00020000);
 #endif
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
 
@@ -623,8 +641,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   // (issue_piece), which the step loop places BETWEEN the MFMA groups of the step before - a wave issues in
   // order, and a piece takes ~100 cycles to get through the texture path when the CU is filling LDS
   // at its rate; issued in a block ahead of the MFMAs, the pieces of a step hold the wave's matrix pipe idle.
-  int va[AP], vb[BP];
+  int va[AP];
+  int soffA = 0, soffB = 0;      // scalar offsets of the step (buffer soffset operand)
   auto prep_step = [&](int k0) {
+    soffB = k0 * 2;
+    if constexpr (FASTK) {
+      // every lane of the step reads the same tap of the same 32-channel block: the tap / channel / source
+      // offset is one scalar, the per-piece work is "row valid for this tap?" -> two VALU instructions
+      const int cl = scb < a.c0 ? scb : scb - a.c0;
+      soffA = ((sky * a.W + skx) * a.ld0 + cl) * 4 + (scb < a.c0 ? 0 : a.src1_delta);
+      const unsigned stap = sky * a.kw + skx;
+#pragma unroll
+      for (int j = 0; j < AP; ++j) {
+        const int bad = __builtin_amdgcn_sbfe((int)(unsigned)tapok[j], stap, 1u);   // -1: tap outside the image (or row past M)
+        va[j] = (bad & (int)0x80000000) | rp0[j];
+      }
+      if (++skx == a.kw) {
+        skx = 0;
+        if (++sky == a.kh) {
+          sky = 0;
+          scb += BK;
+        }
+      }
+      return;
+    }
+    if constexpr (!FASTK) {
+    soffA = 0;
     // channel-block order: this unit's channel can lie in the zero padding of the last block;
     // tap order: the K tail of the last step
     const bool kok = a.korder ? kc < a.ctot : k0 + kg * 8 < a.K;
@@ -658,17 +700,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       }
       kc = cn;
     }
-#pragma unroll
-    for (int j = 0; j < BP; ++j) vb[j] = colbase[j] + k0 * 2;
+    }
   };
   auto issue_piece = [&](int stg, int pc) {
 #ifdef VFML_EXPERIMENT_NOLOAD
     return;
 #endif
     if (pc < AP)
-      dma16(r0, va[pc < AP ? pc : 0], smem_raw + stg * STG + wave * (8 * 128) + pc * (8 * NW * 128));
+      dma16(r0, va[pc < AP ? pc : 0], soffA, smem_raw + stg * STG + wave * (8 * 128) + pc * (8 * NW * 128));
     else if (pc < AP + BP)
-      dma16(rb, vb[pc >= AP && pc < AP + BP ? pc - AP : 0], smem_raw + stg * STG + ASZ + wave * (8 * 128) + (pc - AP) * (8 * NW * 128));
+      dma16(rb, colbase[pc >= AP && pc < AP + BP ? pc - AP : 0], soffB,
+            smem_raw + stg * STG + ASZ + wave * (8 * 128) + (pc - AP) * (8 * NW * 128));
   };
   auto issue_all = [&](int stg) {
 #pragma unroll
@@ -710,11 +752,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          constexpr int GROUPS = 2 * TM * TN;
+#ifndef VFML_ISSUE_GROUPS
+#define VFML_ISSUE_GROUPS (TM * TN)      // the first half of the step: the second half covers the pieces' L2 latency
+#endif
+          constexpr int GROUPS = VFML_ISSUE_GROUPS;
           const int g = (ks * TM + i) * TN + j;
-          // spread AP+BP pieces over the GROUPS groups (the first groups get one more when it does not divide)
+          // spread AP+BP pieces over the first GROUPS groups (the first groups get one more when it does not divide)
           constexpr int PER = (AP + BP + GROUPS - 1) / GROUPS;
-          if (issue) {
+          if (issue && g < GROUPS) {
 #pragma unroll
             for (int q = 0; q < PER; ++q) issue_piece(lstg, g * PER + q);
           }
@@ -859,7 +904,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool PERSIST>
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
   constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
@@ -870,7 +915,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   a.ntiles = (a.cout + TBN - 1) / TBN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -882,14 +927,19 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.mtiles * a.ntiles;
   const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
   const int grid = (int)(PERSIST && total > slots ? slots : total);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
 template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
-  if (a.direct) return launch_dma_k<2, 2, 2, 2, true>(a, s);   // (the one persistent tile shape that does not spill)
-  return launch_dma_k<TM, TN, WM, WN, false>(a, s);
+  if (a.direct)     // (128 x 128: the one persistent tile shape that does not spill)
+    return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
+  if constexpr (WM * WN == 4 && TM * TN >= 2) {   // the shapes the dispatcher picks by itself
+    if (a.fastk) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
+  }
+  a.fastk = 0; a.abias = 0;
+  return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
 }
 
 template <int BN, int WM, int WN, bool BIGC, bool IN16>
@@ -1109,7 +1159,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_ADD_AUX, "vfml_conv2d_split: bad epilogue");
 
   SplitArgs a;
-  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0;
+  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;
@@ -1167,6 +1217,18 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                  "vfml_conv2d_split: channel-block order needs w_hi and w_lo within 1 GiB of each other");
     if (dma_ok && (k_order == VFML_KORDER_CBLOCK || (!no_dma && bn == 128))) {
       a.wbase = wb; a.whi_off = (int)(ph - wb); a.wlo_off = (int)(pl - wb); a.bytesb = (int)ext;
+      {
+        static const int no_fastk = getenv("VFML_NO_FASTK") ? atoi(getenv("VFML_NO_FASTK")) : 0;
+        const int64_t abias = ((int64_t)d->pad_h * d->w + d->pad_w) * d->ld0 * 4;
+        // (for a 1x1 convolution over whole 32-channel blocks the two K orders are the same bytes)
+        const bool cblock = k_order == VFML_KORDER_CBLOCK || (a.pointwise && (d->c0 + d->c1) % BK == 0);
+        a.fastk = !no_fastk && cblock && d->c0 % BK == 0 && (d->c0 + d->c1) % BK == 0 &&
+                  (!two || (d->ld1 == d->ld0 && a.d1off >= a.d0off)) && d->kh * d->kw <= 32 &&
+                  (int64_t)a.bytes0 + abias < (1ll << 31);
+        if (a.fastk) a.korder = VFML_KORDER_CBLOCK;
+        a.abias = a.fastk ? (int)abias : 0;
+        a.src1_delta = two ? (a.d1off - a.d0off) * 4 : 0;
+      }
       static const int direct_min = getenv("VFML_DIRECT_MIN") ? atoi(getenv("VFML_DIRECT_MIN")) : 1024;
       a.direct = (d->epilogue == VFML_EPI_NONE || d->epilogue == VFML_EPI_RELU) && !d->addend && out_fmt == VFML_FMT_F32 &&
                  d->cout >= direct_min && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&

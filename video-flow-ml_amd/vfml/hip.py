@@ -152,7 +152,7 @@ def profile_end():
     return out
 
 
-def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False):
+def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False):
     """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
     the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
     split kernel for cout > 64 is not modelled)."""
@@ -161,12 +161,13 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         return f"conv_gemm_kernel<{tile}>"
     dma = in16 and (order == KORDER_CBLOCK or (cout > 64 and not os.environ.get("VFML_NO_DMA")))
     if dma:     # split-f16, LDS-DMA staged
+        fk = "true" if fastk else "false"       # uniform-step loader (SplitArgs::fastk)
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
-            return "conv_gemm_dma_kernel<2, 2, 2, 2, true>"          # persistent GEMM form
+            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}>"          # persistent GEMM form
         if cout <= 32:
-            return "conv_gemm_dma_kernel<1, 1, 4, 1, false>"
+            return "conv_gemm_dma_kernel<1, 1, 4, 1, false, false>"
         if cout <= 64:
-            return "conv_gemm_dma_kernel<2, 1, 2, 2, false>"
+            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}>"
         def cost(tbm, tbn, mf, eff):
             tiles = -(-m // tbm) * -(-cout // tbn)
             return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
@@ -177,7 +178,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         for c, name in cands[1:]:
             if c < best:
                 best, t = c, name
-        return f"conv_gemm_dma_kernel<{t}, false>"
+        return f"conv_gemm_dma_kernel<{t}, false, {fk}>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
 
@@ -261,8 +262,13 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     launch()
     e1.record()
     plain = (epilogue in (EPI_NONE, EPI_RELU) and addend is None and out_fmt == FMT_F32 and ldo % 4 == 0)
-    _PROFILE.append((conv_variant(cout, is_split, c0 + c1, in_fmt == FMT_S16, n * ho * wo,
-                                  weight.order if is_split else KORDER_TAP, plain),
+    ctot = c0 + c1
+    pointwise = kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0
+    fastk = (is_split and in_fmt == FMT_S16 and (weight.order == KORDER_CBLOCK or (pointwise and ctot % 32 == 0))
+             and c0 % 32 == 0 and ctot % 32 == 0 and kh * kw <= 32 and not os.environ.get("VFML_NO_FASTK")
+             and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
+    _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
+                                  weight.order if is_split else KORDER_TAP, plain, fastk),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
