@@ -1,6 +1,7 @@
 // Correlation-pyramid lookup (K5), coordinate bookkeeping, 8x convex upsampling (K8).
 // All three are HBM/latency-bound gathers: one wave64 per query (lookup) or per coarse pixel
 // (upsample), patches staged through LDS, results written as contiguous runs.
+#include <stdlib.h>
 #include "vfml_common.h"
 
 namespace {
@@ -90,6 +91,93 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
       u[8 + (c & 7)] = ll[0];
     } else {
       o[c] = v;
+    }
+  }
+}
+
+// The same lookup with the radius as a compile-time constant (4: default, 3: --fast): the patch / window
+// index arithmetic becomes multiplications by constants instead of integer divisions (the generic kernel
+// spends more issue slots on `e / psz`, `idx / side`, `c / (win*win)` than on its loads), and a lane
+// produces four consecutive output channels, stored as one 16-byte run (f32) or two 8-byte runs (split rows).
+template <int R, bool OUT16>
+__global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(const LookupArgs a) {
+  constexpr int SIDE = 2 * R + 2, PSZ = SIDE * SIDE, WIN = 2 * R + 1, WW = WIN * WIN;
+  __shared__ float patch[LOOKUP_WAVES][MAX_LEVELS][PSZ];
+  __shared__ float frac[LOOKUP_WAVES][MAX_LEVELS][2];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int q = blockIdx.x * LOOKUP_WAVES + wv;
+  const bool live = q < a.nq;
+  const int map = live ? q / a.q_per_map : 0;
+  const int qq = q - map * a.q_per_map;
+  if (live) {
+    const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
+    const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
+    const int total = a.levels * PSZ;
+    for (int e = lane; e < total; e += 64) {
+      const int l = e / PSZ;
+      const int idx = e - l * PSZ;
+      const int py = idx / SIDE, px = idx - py * SIDE;
+      const float inv = 1.0f / (float)(1 << l);
+      const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
+      const float fx0 = floorf(x), fy0 = floorf(y);
+      const int x0 = (int)fminf(fmaxf(fx0, -65536.f), 65536.f) - R;
+      const int y0 = (int)fminf(fmaxf(fy0, -65536.f), 65536.f) - R;
+      const int xx = x0 + px, yy = y0 + py;
+      float v = 0.f;
+      if (xx >= 0 && xx < a.wl[l] && yy >= 0 && yy < a.hl[l])
+        v = a.pyr[map][l][(int64_t)qq * a.ld[l] + yy * a.wl[l] + xx];
+      patch[wv][l][idx] = v;
+      if (idx == 0) {
+        frac[wv][l][0] = x - fx0;
+        frac[wv][l][1] = y - fy0;
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const int nout = a.levels * WW;
+  float* o = a.out + (int64_t)q * a.ld_out;
+  const int nquads = OUT16 ? ((nout + 7) & ~7) / 4 : (nout + 3) / 4;   // split rows: zero-fill up to a whole unit
+  for (int c4 = lane; c4 < nquads; c4 += 64) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c4 * 4 + k;
+      v[k] = 0.f;
+      if (c < nout) {
+        const int l = c / WW;
+        const int rem = c - l * WW;
+        const int i = rem / WIN, j = rem - i * WIN;  // i: x offset index, j: y offset index
+        const float fx = frac[wv][l][0], fy = frac[wv][l][1];
+        const float* p = &patch[wv][l][j * SIDE + i];
+        const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+        // (same expression, same order as the generic kernel: results are bit-identical)
+        v[k] = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[SIDE] * (wx0 * fy) + p[SIDE + 1] * (fx * fy);
+      }
+    }
+    if (OUT16) {
+      typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
+      const fp16x2_ h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+      const fp16x2_ l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
+      const fp16x2_ l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+      // quad c4 of unit c4/2: hi halves at byte 8*(c4&1) of the 32-byte unit, lo halves 16 bytes further
+      char* u = reinterpret_cast<char*>(o + (c4 >> 1) * 8) + 8 * (c4 & 1);
+      uint2 hv, lv;
+      hv.x = __builtin_bit_cast(unsigned, h0); hv.y = __builtin_bit_cast(unsigned, h1);
+      lv.x = __builtin_bit_cast(unsigned, l0); lv.y = __builtin_bit_cast(unsigned, l1);
+      *reinterpret_cast<uint2*>(u) = hv;
+      *reinterpret_cast<uint2*>(u + 16) = lv;
+    } else {
+      const int c = c4 * 4;
+      if (c + 3 < nout && (((uintptr_t)(o + c)) & 15u) == 0) {
+        f32x4 w = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o + c) = w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (c + k < nout) o[c + k] = v[k];
+      }
     }
   }
 }
@@ -234,8 +322,18 @@ extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, cons
   for (int l = levels; l < MAX_LEVELS; ++l) a.hl[l] = a.wl[l] = a.ld[l] = 0;
   a.levels = levels; a.radius = radius; a.nq = nq; a.q_per_map = q_per_map;
   a.coords = coords; a.ld_coords = ld_coords; a.out = out; a.ld_out = ld_out;
-  hipLaunchKernelGGL(corr_lookup_kernel, dim3((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), dim3(64 * LOOKUP_WAVES), 0,
-                     reinterpret_cast<hipStream_t>(stream), a);
+  const dim3 grid((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), block(64 * LOOKUP_WAVES);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const int generic = getenv("VFML_LOOKUP_GENERIC") ? atoi(getenv("VFML_LOOKUP_GENERIC")) : 0;
+  if (radius == 4 && !generic) {
+    if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, false>), grid, block, 0, st, a);
+  } else if (radius == 3 && !generic) {
+    if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, false>), grid, block, 0, st, a);
+  } else {
+    hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, st, a);
+  }
   return vfml_check_launch("vfml_corr_lookup");
 }
 
