@@ -151,6 +151,25 @@ def test_wide_gemm_persistent_path(gpu, bias, epi):
     assert (got[:, S:] == 7.0).all()          # nothing written past cout
 
 
+def test_gemm_rows_of_a_source_larger_than_one_descriptor(gpu):
+    """1x1 over one split-row source whose rows span 2.2 GB (> the 2 GiB a buffer descriptor covers): the
+    LDS-DMA kernel rebases its descriptor per tile.  (MemFlow's attention read-out: 4.2 GB of attention rows.)"""
+    from vfml import hip
+    g = torch.Generator().manual_seed(22)
+    rows, ld, c, cout = 17000, 32768, 64, 128
+    x = torch.randn(rows, c, generator=g)
+    wt = torch.randn(cout, c, generator=g) / 8.0
+    src = torch.zeros(rows * ld, device=gpu)                       # 2.2 GB, channels 0..63 of every row used
+    hip.to_s16(x.cuda().reshape(-1), rows, c, c, src, ld)
+    out = torch.zeros(rows * cout, device=gpu)
+    hip.conv2d(src, c, ld, rows, 1, 1, as_weight(wt.reshape(-1), cout, "f16x3"), None, cout, 1, 1, out, cout,
+               in_fmt=hip.FMT_S16)
+    ref = (x.double() @ wt.double().t()).float()
+    got = out.view(rows, cout).cpu()
+    assert rel_err(got, ref) < CONV_TOL["f16x3"]
+    assert rel_err(got[-200:], ref[-200:]) < CONV_TOL["f16x3"]      # the rows beyond 2 GiB
+
+
 def s16_decode(flat, rows, ld, c):
     """split rows (FMT_S16) device buffer -> f32 [rows, c] on the host."""
     u = flat.view(torch.float16).view(rows, ld // 8, 2, 8).float().cpu()

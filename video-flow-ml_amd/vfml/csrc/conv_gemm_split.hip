@@ -73,6 +73,7 @@ struct SplitArgs {
   // uniform-step loader of the LDS-DMA kernel (channel-block order, whole 32-channel blocks per source,
   // one row stride): per K step the tap / channel offset is one scalar
   int fastk, abias, src1_delta;
+  int tilebase;   // 1x1 over one source: the source descriptor starts at the tile's first row (sources > 2 GiB)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -559,6 +560,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   int kc, kky, kkx;   // channel within the tap and tap position of k = k0 + 8*kg, advanced by BK per step
   int scb = 0, sky = 0, skx = 0;   // uniform-step loader: channel block and tap of the step (scalars)
   int m0, n0;
+#ifdef VFML_EXPERIMENT_ZERODESC   // timing only: every DMA is range-checked away, the instruction stream stays
+  __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, 0, 0x00020000);
+#else
+  __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(const_cast<float*>(a.in0)) - a.abias, 0, a.bytes0 + a.abias, 0x00020000);
+#endif
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
+
   auto setup = [&](int tl) {
     int nt, mt;
     if (a.ntiles >= 8) {
@@ -586,8 +595,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       if (a.pointwise) {       // 1x1, stride 1, no padding: output pixel m IS input pixel m (GEMM rows)
         if (m < a.M) {
           tapok[j] = 1ull;
-          rp0[j] = (m * a.ld0 + a.d0off) * 4;
-          rp1[j] = (m * a.ld1 + a.d1off) * 4;
+          const int mrow = a.tilebase ? m - m0 : m;      // tilebase: offsets from the tile's first row
+          rp0[j] = (mrow * a.ld0 + a.d0off) * 4;
+          rp1[j] = (mrow * a.ld1 + a.d1off) * 4;
         }
       } else if (m < a.M) {
         const int hw = a.ho * a.wo;
@@ -627,15 +637,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       const int col = n0 + 8 * NW * j + lrow;
       colbase[j] = col < a.cout ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : 0x40000000;
     }
+    if (a.tilebase) {
+      // GEMM rows of a source that can exceed what one descriptor spans: base it at this tile's first row
+      const int rows = a.M - m0 < TBM ? a.M - m0 : TBM;
+      r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0) + (int64_t)m0 * a.ld0, 0,
+                                             ((rows - 1) * a.ld0 + a.d0off + a.c0) * 4, 0x00020000);
+    }
   };
-
-#ifdef VFML_EXPERIMENT_ZERODESC   // timing only: every DMA is range-checked away, the instruction stream stays
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, 0, 0x00020000);
-#else
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char*>(const_cast<float*>(a.in0)) - a.abias, 0, a.bytes0 + a.abias, 0x00020000);
-#endif
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
 
   // The loads of a K step: offsets first (prep_step, VALU), then one LDS-DMA instruction per piece
   // (issue_piece), which the step loop places BETWEEN the MFMA groups of the step before - a wave issues in
@@ -1144,10 +1152,16 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(ho > 0 && wo > 0, "vfml_conv2d_split: empty output");
   const int64_t M64 = (int64_t)d->n * ho * wo;
   VFML_REQUIRE(M64 < (1ll << 31) - BM, "vfml_conv2d_split: too many output pixels");
-  {
+  // 1x1 / stride 1 over ONE split-row source (GEMM rows): the LDS-DMA kernel bases its descriptor at each
+  // tile's first row, so the source may be of any size (the MemFlow attention matrix is 4.2 GB)
+  const bool tilebase = in16 && !two && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 &&
+                        (int64_t)256 * d->ld0 * 4 < (1ll << 31);
+  if (!tilebase) {
     const int64_t px = (int64_t)d->n * d->h * d->w + (int64_t)(d->pad_h + 1) * d->w + d->pad_w;
     VFML_REQUIRE(px * d->ld0 * 4 < (1ll << 30) && (!two || px * d->ld1 * 4 < (1ll << 30)),
                  "vfml_conv2d_split: a source spans >= 1 GiB");
+  }
+  {
     VFML_REQUIRE(((int64_t)d->cout + 128) * kp * 2 < (1ll << 30), "vfml_conv2d_split: weight planes too large");
   }
   if (d->epilogue == VFML_EPI_GRU_ZR || d->epilogue == VFML_EPI_TANH_RELU)
@@ -1165,11 +1179,13 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;
   const int64_t e0 = (d->in0 - base) + ((int64_t)d->n * d->h * d->w - 1) * d->ld0 + d->c0;
   const int64_t e1 = two ? (d->in1 - base) + ((int64_t)d->n * d->h * d->w - 1) * d->ld1 + d->c1 : 0;
-  VFML_REQUIRE((e0 > e1 ? e0 : e1) * 4 < (1ll << 31),
+  VFML_REQUIRE(tilebase || (e0 > e1 ? e0 : e1) * 4 < (1ll << 31),
                "vfml_conv2d_split: in0 and in1 must be slices of one buffer (< 2 GiB apart)");
   a.in0 = base; a.in1 = base;
   a.d0off = (int)(d->in0 - base); a.d1off = two ? (int)(d->in1 - base) : 0;
-  a.bytes0 = (int)((e0 > e1 ? e0 : e1) * 4);
+  const bool fits_one = (e0 > e1 ? e0 : e1) * 4 < (1ll << 31) && (int64_t)d->n * d->h * d->w * d->ld0 * 4 < (1ll << 30);
+  a.bytes0 = fits_one ? (int)((e0 > e1 ? e0 : e1) * 4) : 0;
+  a.tilebase = 0;
   a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo; a.bias = d->bias;
   a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
   a.addend = d->addend; a.ld_addend = d->ld_addend;
@@ -1215,8 +1231,9 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
     const bool dma_ok = ext < (1ll << 30);
     VFML_REQUIRE(k_order == VFML_KORDER_TAP || dma_ok,
                  "vfml_conv2d_split: channel-block order needs w_hi and w_lo within 1 GiB of each other");
-    if (dma_ok && (k_order == VFML_KORDER_CBLOCK || (!no_dma && bn == 128))) {
+    if (dma_ok && (k_order == VFML_KORDER_CBLOCK || !no_dma)) {   // every split-row source goes through LDS-DMA
       a.wbase = wb; a.whi_off = (int)(ph - wb); a.wlo_off = (int)(pl - wb); a.bytesb = (int)ext;
+      a.tilebase = tilebase;
       {
         static const int no_fastk = getenv("VFML_NO_FASTK") ? atoi(getenv("VFML_NO_FASTK")) : 0;
         const int64_t abias = ((int64_t)d->pad_h * d->w + d->pad_w) * d->ld0 * 4;
@@ -1269,6 +1286,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         default: return launch_dma<2, 2, 2, 2>(a, s);
       }
     }
+    VFML_REQUIRE(fits_one, "vfml_conv2d_split: a source spans >= 1 GiB (only the LDS-DMA kernel takes larger GEMM sources)");
     if (bn == 128) {
       a.ntiles = (d->cout + 127) / 128;
       return launch<128, 2, 2, true, true>(a, s);

@@ -238,11 +238,10 @@ class MemFlowNetHIP(MOFNetHIP):
                 wgt, b = P[f"{ub}.value"]
                 hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, val, AD, in0_off=MF, in_fmt=AF)
                 vt.fill_transposed(val, Pn, ld=AD, scale=16.0)
-                for r0 in range(0, Pn, rows_per_call):      # rows as the batch axis: 1x1 "images"
-                    nr = min(rows_per_call, Pn - r0)
-                    hip.conv2d(attn, P8, ldA, nr, 1, 1, vt, None, AD, 1, 1, G, GLD, in0_off=r0 * ldA,
-                               out_off=r0 * GLD + MT, out_scale=gamma, epilogue=hip.EPI_ADD_AUX,
-                               aux0=G, ld_aux0=GLD, aux0_off=r0 * GLD + MF, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                # rows as the batch axis (1x1 "images"): one GEMM over the whole 4.2 GB attention matrix - the
+                # LDS-DMA kernel bases its source descriptor at each tile's first row
+                hip.conv2d(attn, P8, ldA, Pn, 1, 1, vt, None, AD, 1, 1, G, GLD, out_off=MT, out_scale=gamma,
+                           epilogue=hip.EPI_ADD_AUX, aux0=G, ld_aux0=GLD, aux0_off=MF, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
                     hip.conv2d(G, 128, GLD, 1, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
