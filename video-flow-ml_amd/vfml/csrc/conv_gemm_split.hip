@@ -10,19 +10,21 @@
 // scaled by a power of two at split time so that its lo halves are normal numbers; the epilogue
 // multiplies the accumulator by the inverse (exact).
 //
-// Activations stay fp32 NHWC in HBM and are split while being staged into LDS; weights (and the
-// pooled target features of the correlation GEMM) are pre-split once by vfml_split_f16 into two
-// f16 planes [cout][Kp], Kp = K rounded up to 32 (one K step), zero padded.
-//
-// Tiling: 128 pixels x BN channels per 256-thread workgroup, K stepped by 32.  LDS image per
-// operand plane: [k/8][row] 16-byte units (8 halves), row stride padded by 2 units: the staging
-// write of 8 consecutive lanes (4 k-groups x 2 rows) covers all 32 banks, a wave's fragment read is
-// 32 consecutive units (conflict-free ds_read_b128) and is exactly one MFMA operand
-// (lane l: row l&31, k = 8*(l>>5)+j).
-// Pipeline: two register staging sets; the global loads of K step k+2 are issued before the MFMAs
-// of step k, the (already landed) loads of step k+1 are split and written to the other LDS
-// buffer after them; one barrier per K step.  Loads are unconditional (padding taps / K tails read
-// a zero line) so that no load sits behind a divergent branch.
+// Two kernels share the arithmetic and the epilogue:
+//  * conv_gemm_dma_kernel   - sources in the split-row format (VFML_FMT_S16: per pixel and 8-channel
+//    group 16 B of hi halves then 16 B of lo halves), staged into LDS by `buffer_load ... lds` (LDS-DMA):
+//    every update-block convolution, the correlation GEMMs, the MemFlow attention GEMMs.  Described
+//    in front of the kernel.
+//  * conv_gemm_split_kernel - fp32 NHWC sources (encoders, the 4-channel flow convolution), split
+//    while register-staged into LDS.  Tiling: 128 pixels x BN channels per 256-thread workgroup, K
+//    stepped by 32; LDS image per operand plane [k/8][row] 16-byte units (8 halves), row stride padded
+//    by 2 units (staging writes cover all 32 banks, a wave's fragment read is 32 consecutive units =
+//    one MFMA operand, conflict-free).  Two register staging sets: the global loads of K step k+2 are
+//    issued before the MFMAs of step k, the landed loads of step k+1 are split and written to the other
+//    LDS buffer after them; one barrier per K step.  Loads are unconditional (padding taps / K tails
+//    read out-of-range buffer offsets = zeros) so that no load sits behind a divergent branch.
+// Weights (and the pooled target features of the correlation GEMM) are pre-split once by
+// vfml_split_f16 into two f16 planes [cout][Kp], zero padded.
 // Epilogue: the accumulator tile is transposed through LDS and written as float4 rows (bias,
 // activation and the GRU gate math applied on the way).
 #include <hip/hip_fp16.h>
@@ -1223,15 +1225,12 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   }
   if (in16) {   // split-row sources: every slice is a multiple of 8 channels and >= one K step wide
     // LDS-DMA kernel when both weight planes fit one descriptor window (< 1 GiB)
-    static const int no_dma = getenv("VFML_NO_DMA") ? atoi(getenv("VFML_NO_DMA")) : 0;
     const char* ph = (const char*)w_hi;
     const char* pl = (const char*)w_lo;
     const char* wb = ph < pl ? ph : pl;
     const int64_t ext = (ph < pl ? pl - ph : ph - pl) + (int64_t)d->cout * kp * 2;
     const bool dma_ok = ext < (1ll << 30);
-    VFML_REQUIRE(k_order == VFML_KORDER_TAP || dma_ok,
-                 "vfml_conv2d_split: channel-block order needs w_hi and w_lo within 1 GiB of each other");
-    if (dma_ok && (k_order == VFML_KORDER_CBLOCK || !no_dma)) {   // every split-row source goes through LDS-DMA
+    if (dma_ok) {   // every split-row source goes through the LDS-DMA kernel
       a.wbase = wb; a.whi_off = (int)(ph - wb); a.wlo_off = (int)(pl - wb); a.bytesb = (int)ext;
       a.tilebase = tilebase;
       {
@@ -1286,16 +1285,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         default: return launch_dma<2, 2, 2, 2>(a, s);
       }
     }
-    VFML_REQUIRE(fits_one, "vfml_conv2d_split: a source spans >= 1 GiB (only the LDS-DMA kernel takes larger GEMM sources)");
-    if (bn == 128) {
-      a.ntiles = (d->cout + 127) / 128;
-      return launch<128, 2, 2, true, true>(a, s);
-    } else if (bn == 64) {
-      a.ntiles = (d->cout + 63) / 64;
-      return launch<64, 2, 2, true, true>(a, s);
-    }
-    a.ntiles = 1;
-    return launch<32, 4, 1, true, true>(a, s);
+    vfml_set_error("vfml_conv2d_split: split-row sources need w_hi and w_lo within 1 GiB of each other (one allocation)");
+    return 1;
   }
   if (bn == 128) {
     a.ntiles = (d->cout + 127) / 128;

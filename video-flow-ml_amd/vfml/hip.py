@@ -159,7 +159,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
     tile = "128, 2, 2" if cout > 64 else ("64, 2, 2" if cout > 32 else "32, 4, 1")
     if not split:
         return f"conv_gemm_kernel<{tile}>"
-    dma = in16 and (order == KORDER_CBLOCK or not os.environ.get("VFML_NO_DMA"))
+    dma = in16
     if dma:     # split-f16, LDS-DMA staged
         fk = "true" if fastk else "false"       # uniform-step loader (SplitArgs::fastk)
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
