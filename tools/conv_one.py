@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, 
 import torch
 from vfml import hip
 n, h, w, cin, cout, kh, kw = 3, 135, 240, 512, 256, 1, 5
-x = torch.randn(n * h * w * cin, device="cuda")
+ld = int(os.environ.get('LD', 768))
+x = torch.randn(n * h * w * ld, device="cuda")
 wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
 b = torch.randn(cout, device="cuda")
 from vfml.weights import pack_conv_weight
@@ -16,9 +17,9 @@ out = torch.empty(n * h * w * cout, device="cuda")
 fmt = hip.FMT_S16 if os.environ.get("S16", "1") == "1" else hip.FMT_F32
 if fmt == hip.FMT_S16:
     x16 = torch.empty_like(x)
-    hip.to_s16(x, n * h * w, cin, cin, x16, cin)
+    hip.to_s16(x, n * h * w, ld, ld, x16, ld)
     x = x16
 for _ in range(5):
-    hip.conv2d(x, cin, cin, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
+    hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
                in_fmt=fmt, out_fmt=fmt)
 torch.cuda.synchronize()
