@@ -179,3 +179,36 @@ def test_longest_window_and_reference_api_with_padding(gpu, tmp_path, monkeypatc
     pad = mo.InputPadder(x.shape[-2:])
     ref = pad.unpad(ora(pad.pad(x), {})[0])[0, 8].permute(1, 2, 0).numpy()      # shape[1]//2 of 16 flows
     assert np.sqrt(((got - ref) ** 2).sum(-1)).mean() < EPE_TOL
+
+
+def test_host_array_api_fast_path_is_exact_and_sees_edits(gpu, tmp_path, monkeypatch):
+    """The reference's call shape (list of uint8 numpy frames in, numpy field out) keyed on frame CONTENT:
+    bit-identical to the float32 path it replaces, along a sliding loop, for tiles, and after a frame is
+    edited in place (its hash, hence its cache entries, change)."""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.flow_inference import VideoFlowInference
+    from vfml import get_cfg
+    from vfml.synth import synthetic_clip
+    from vfml.weights import write_seeded_checkpoint
+    write_seeded_checkpoint(str(tmp_path), get_cfg(), seed=0)
+    monkeypatch.chdir(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = VideoFlowInference("cuda", sequence_length=5)
+        eng.load_model()
+    proc = eng.get_processor()
+    frames = synthetic_clip(7, 128, 160)
+
+    def float_path(fr, i):       # what compute_optical_flow did before the fast path (and still does for float frames)
+        return proc.core.compute_flow_from_tensor(proc.prepare_frame_sequence(fr, i)).permute(1, 2, 0).cpu().numpy()
+
+    for i in (0, 1, 3, 4, 6):
+        assert proc._flow_from_host_u8(frames, i) is not None
+        assert np.array_equal(eng.compute_optical_flow(frames, i), float_path(frames, i))
+    frames[4][10:40, 20:60] = 255 - frames[4][10:40, 20:60]          # in-place edit of a cached frame
+    assert np.array_equal(eng.compute_optical_flow(frames, 4), float_path(frames, 4))
+    assert np.array_equal(eng.compute_optical_flow(frames, 3), float_path(frames, 3))
+    # float frames and sizes that need padding take the reference's own path
+    assert proc._flow_from_host_u8([f.astype(np.float32) for f in frames], 3) is None
+    assert proc._flow_from_host_u8(synthetic_clip(5, 132, 164), 2) is None

@@ -5,10 +5,24 @@ window selection and padding asymmetry (:133-147), u8 -> float32 /255 and HWC->C
 fixed 1280x1280 row-major tiles with ragged edge tiles and hard seams (:73-110, :231-283),
 [H,W,2] float32 numpy output (:185).
 """
+import collections
+import hashlib
+
 import numpy as np
 import torch
 
 from .videoflow_core import VideoFlowCore
+
+try:                                    # content keys of host frames: xxh3 runs at memory speed
+    import xxhash
+
+    def _digest(buf):
+        return xxhash.xxh3_128_digest(buf)
+except ImportError:                     # pragma: no cover - xxhash is part of the image
+    def _digest(buf):
+        return hashlib.blake2b(buf, digest_size=16).digest()
+
+HOST_FRAME_CACHE = 24                   # uint8 frames kept in HBM for the host-array API (LRU)
 
 
 class VideoFlowProcessor:
@@ -22,6 +36,7 @@ class VideoFlowProcessor:
         self.architecture = architecture
         self.variant = variant
         self.core = VideoFlowCore(device, fast_mode, dataset, architecture, variant)
+        self._dev_frames = collections.OrderedDict()      # content key -> uint8 [H,W,3] device tensor
         print("VideoFlow Processor initialized:")
         for label, value in (("Device", device), ("Fast mode", fast_mode), ("Tile mode", tile_mode),
                              ("Sequence length", sequence_length), ("Dataset", dataset),
@@ -78,9 +93,47 @@ class VideoFlowProcessor:
         if not self.core.is_model_loaded():
             raise RuntimeError("Model not loaded. Call load_model() first.")
 
+    def _flow_from_host_u8(self, frames, frame_idx):
+        """The reference's host-array call (list of numpy frames in, numpy field out) without its per-call
+        cost: the reference converts, stacks and uploads T float32 frames (124 MB at 1080p) for every
+        field and T-1 of them are the frames of the previous call (:150-161).  Here every uint8 frame of
+        the window is identified by a 128-bit hash of its CONTENT (3 ms for five 1080p frames; an in-place
+        edit of a frame changes its key), uploaded once as uint8, and the engine's per-frame / per-pair
+        caches are keyed on the same hash - so a sliding loop over host frames runs at the resident
+        rate.  Same pixels, same /255, same network: bit-identical to the float path (tests).  Returns
+        None when the fast path does not apply (float frames, sizes that need padding, CPU)."""
+        model = self.core.model
+        if not (str(self.device).startswith('cuda') and hasattr(model, "forward_u8")):
+            return None
+        ids = self.window_indices(len(frames), frame_idx)
+        f0 = frames[ids[0]]
+        if not all(isinstance(frames[i], np.ndarray) and frames[i].dtype == np.uint8 and frames[i].ndim == 3 and
+                   frames[i].shape == f0.shape for i in set(ids)):
+            return None
+        H, W, C = f0.shape
+        if C != 3 or H % 8 or W % 8:
+            return None
+        keys = {}
+        for i in set(ids):
+            a = np.ascontiguousarray(frames[i])
+            k = ("host-u8", _digest(memoryview(a).cast("B")), a.shape)
+            keys[i] = k
+            if k in self._dev_frames:
+                self._dev_frames.move_to_end(k)
+            else:
+                self._dev_frames[k] = torch.from_numpy(a).to(self.device)
+                while len(self._dev_frames) > HOST_FRAME_CACHE:
+                    self._dev_frames.popitem(last=False)
+        win = torch.stack([self._dev_frames[keys[i]] for i in ids])
+        flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=[keys[i] for i in ids])
+        return flows[0, flows.shape[1] // 2].permute(1, 2, 0).cpu().numpy()
+
     def compute_optical_flow(self, frames, frame_idx):
         """-> numpy [H,W,2] float32, pixels."""
         self._require_model()
+        fast = self._flow_from_host_u8(frames, frame_idx)
+        if fast is not None:
+            return fast
         flow = self.core.compute_flow_from_tensor(self.prepare_frame_sequence(frames, frame_idx))
         return flow.permute(1, 2, 0).cpu().numpy()
 
@@ -96,6 +149,10 @@ class VideoFlowProcessor:
                     tile_pbar.update(n)
 
         step("Preparing frames", reset=True)
+        fast = self._flow_from_host_u8(frames, frame_idx)
+        if fast is not None:
+            step("Completed", 4)
+            return fast
         batch = self.prepare_frame_sequence(frames, frame_idx)
         step("Running VideoFlow", 2)
         flow = self.core.compute_flow_from_tensor(batch)
