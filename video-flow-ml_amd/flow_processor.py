@@ -138,21 +138,24 @@ def main(argv=None):
     eng.load_model()
     proc = eng.get_processor()
     clip = proc.upload_clip(frames)
+    save_format = args.save_flow or 'npz'
+    # rank 0 owns the cache files; the writer's threads compress finished fields while the GPU computes the
+    # next ones (one rank, whole frames) or after the gather (several ranks / tiles)
+    writer = AsyncFlowCacheWriter(cache_dir, save_format, workers=min(16, os.cpu_count() or 1),
+                                  num_lods=0 if args.skip_lods else 5, manager=mgr) if rank == 0 else None
     t0 = time.time()
-    flows = run_sharded(proc, clip, range(n), tile_mode=args.tile and not memflow, rank=rank, world=world)
+    run_sharded(proc, clip, range(n), tile_mode=args.tile and not memflow, rank=rank, world=world,
+                on_field=(lambda k, field: writer.submit(field, k)) if writer is not None else None)
     if str(device).startswith('cuda'):
         torch.cuda.synchronize()
     dt = time.time() - t0
     if rank == 0:
         log(f"{n} flow fields ({width}x{height}, seq {args.sequence_length}) in {dt:.2f} s = {n / dt:.2f} fields/s "
             f"on {world} GPU(s)")
-        save_format = args.save_flow or 'npz'
-        t1 = time.time()
-        with AsyncFlowCacheWriter(cache_dir, save_format, workers=min(16, os.cpu_count() or 1),
-                                  num_lods=0 if args.skip_lods else 5, manager=mgr) as writer:
-            for i in range(n):
-                writer.submit(flows[i], i)
-        log(f"Flow cache written: {cache_dir} ({n / max(time.time() - t1, 1e-9):.1f} fields/s incl. LODs)")
+        writer.close()
+        dt_all = time.time() - t0
+        log(f"Flow cache written: {cache_dir} ({n / max(dt_all, 1e-9):.1f} fields/s end to end, incl. "
+            f"{'no ' if args.skip_lods else ''}LODs)")
         if not args.interactive:
             log("note: video encoding / composition is out of scope for this build; the flow cache is the output")
     if torch.distributed.is_initialized():

@@ -20,11 +20,50 @@ def item_numel(height, width, tile):
     return h * w * 2
 
 
-def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None):
+def _run_streaming(proc, clip, frame_indices, on_field):
+    """One rank, whole frames: every field goes to host memory as soon as it is finished (pinned staging
+    ring, the copy of field i overlaps the computation of field i+1) and is handed to `on_field(k, array)`
+    - the cache writer of flow_processor.py - while the GPU keeps computing."""
+    H, W = clip.shape[1], clip.shape[2]
+    out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32)
+    on_gpu = clip.is_cuda
+    ring = [torch.empty((H, W, 2), dtype=torch.float32).pin_memory() for _ in range(3)] if on_gpu else None
+    events = [None] * 3
+    pending = []                                       # (slot in out, ring index)
+
+    def drain(limit):
+        while len(pending) > limit:
+            k, r = pending.pop(0)
+            events[r].synchronize()
+            out[k] = ring[r].numpy()
+            on_field(k, out[k])
+
+    for k, f in enumerate(frame_indices):
+        flow = proc.compute_optical_flow_resident(clip, f)
+        if not on_gpu:
+            out[k] = flow.numpy()
+            on_field(k, out[k])
+            continue
+        drain(2)                                       # the ring slot about to be reused is free
+        r = k % 3
+        ring[r].copy_(flow, non_blocking=True)
+        events[r] = torch.cuda.Event()
+        events[r].record()
+        pending.append((k, r))
+        drain(1)                                       # hand over field k-1 while field k is in flight
+    drain(0)
+    return out
+
+
+def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None, on_field=None):
     """Compute the flow field of every frame in `frame_indices` of the device-resident uint8 clip
-    [F,H,W,3].  Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2]; None elsewhere."""
+    [F,H,W,3].  Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2]; None elsewhere.
+    `on_field(k, field)` (optional) is called on rank 0 for every finished field, k = position in
+    `frame_indices`: as the fields finish when one rank computes whole frames, after the gather otherwise."""
     frame_indices = list(frame_indices)
     F, H, W = clip.shape[0], clip.shape[1], clip.shape[2]
+    if on_field is not None and world == 1 and not tile_mode:
+        return _run_streaming(proc, clip, frame_indices, on_field)
     tiles = _tiles(proc, W, H, tile_mode)
     items = vdist.work_items(frame_indices, len(tiles), tile_major=True)   # keeps the per-crop caches hot
     bounds = [vdist.shard_bounds(len(items), r, world) for r in range(world)]
@@ -54,4 +93,7 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
                 y, x, th, tw = tile['y'], tile['x'], tile['height'], tile['width']
                 out[slot[f], y:y + th, x:x + tw] = host[off:off + n].reshape(th, tw, 2)
             off += n
+    if on_field is not None:
+        for k in range(len(frame_indices)):
+            on_field(k, out[k])
     return out
