@@ -212,3 +212,51 @@ def test_host_array_api_fast_path_is_exact_and_sees_edits(gpu, tmp_path, monkeyp
     # float frames and sizes that need padding take the reference's own path
     assert proc._flow_from_host_u8([f.astype(np.float32) for f in frames], 3) is None
     assert proc._flow_from_host_u8(synthetic_clip(5, 132, 164), 2) is None
+
+
+def test_full_size_properties_1080p_and_4k_tiles(gpu):
+    """BASELINE's full sizes, through properties that need no oracle run: at 1080p (config 2) the sliding
+    caches give bit-identical fields to encoding the window from scratch, a second run is bit-identical
+    (no atomics, no order dependence), and the host-array API equals the resident path; at 4K --tile
+    (config 3) the runner's pasted frame equals the six tiles computed one by one, ragged edge tiles included.
+    (The oracle comparison at 1080p itself is part of every bench.py run: `cpu_baseline.epe_mean_px`.)"""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.runner import run_sharded
+    from vfml.synth import synthetic_clip
+    net, _ = _pair()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=5)
+    proc.core.model = net
+    frames = synthetic_clip(7, 1080, 1920)
+    clip = proc.upload_clip(frames)
+    a = [proc.compute_optical_flow_resident(clip, i).clone() for i in (2, 3, 4)]      # sliding, cached
+    net.clear_feature_cache()
+    b, _ = net.forward_u8(clip[proc.window_indices(7, 4)])                             # from scratch
+    assert torch.equal(a[2], b[0, 3].permute(1, 2, 0))
+    assert torch.isfinite(a[2]).all() and float(a[2].abs().max()) < 2000.0
+    again = proc.compute_optical_flow_resident(clip, 4)
+    assert torch.equal(a[2], again)
+    assert np.array_equal(proc.compute_optical_flow(frames, 3), a[1].cpu().numpy())   # host-array API
+    del a, b, again
+    net.clear_feature_cache()
+    torch.cuda.empty_cache()
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        tproc = VideoFlowProcessor("cuda", tile_mode=True, sequence_length=5)
+    tproc.core.model = net
+    big = synthetic_clip(5, 2160, 3840)
+    bclip = tproc.upload_clip(big)
+    pasted = run_sharded(tproc, bclip, [2], tile_mode=True)[0]
+    tiles = tproc.calculate_tile_grid(3840, 2160)[4]
+    assert [(t['width'], t['height']) for t in tiles] == [(1280, 1280)] * 3 + [(1280, 880)] * 3
+    for t in tiles:
+        net.clear_feature_cache()
+        crop = bclip[tproc.window_indices(5, 2)][:, t['y']:t['y'] + t['height'], t['x']:t['x'] + t['width']].contiguous()
+        one, _ = net.forward_u8(crop)
+        ref = one[0, 3].permute(1, 2, 0).cpu().numpy()
+        assert np.array_equal(pasted[t['y']:t['y'] + t['height'], t['x']:t['x'] + t['width']], ref)
+    net.clear_feature_cache()
+    torch.cuda.empty_cache()
