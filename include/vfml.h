@@ -90,7 +90,13 @@ int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_l
  *                       kp = kh*kw*roundup32(c0+c1); split-row sources only.  All taps of one
  *                       32-channel block are consecutive K steps, so the kh*kw reads of an input line
  *                       happen while it is still in L2 (tap-major order re-reads it ctot/32 steps later,
- *                       from the Infinity Cache or HBM).  For 1x1 convolutions the two orders coincide. */
+ *                       from the Infinity Cache or HBM).  For 1x1 convolutions the two orders coincide.
+ * Split-row sources (in_fmt VFML_FMT_S16) are staged by LDS-DMA: c0, c1, ld0, ld1 multiples of 8, at least 32
+ * channels, and w_hi / w_lo within 1 GiB of each other (halves of one allocation, as vfml_split_f16's callers
+ * make them) because both planes are read through one buffer descriptor.  A 1x1 / stride-1 convolution over ONE
+ * split-row source (GEMM rows) may span any number of bytes (the descriptor is rebased per tile); every other
+ * source must span < 1 GiB, both sources of a two-source call must lie within 2 GiB of each other.  Plain f32
+ * outputs at least 1024 channels wide (cout % 4 == 0) take the persistent GEMM form of the kernel. */
 enum { VFML_KORDER_TAP = 0, VFML_KORDER_CBLOCK = 1 };
 
 /* f32 rows [rows][c] (row stride ld_src floats) -> split rows [rows][ld_dst] (VFML_FMT_S16); c % 4 == 0. */
