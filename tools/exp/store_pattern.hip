@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void store_pattern(float* out, int rows, int c
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     step = (G - xcd + 7) >> 3; tile = start + lw; end = start + q + (xcd < r ? 1 : 0);
   } else { tile = blockIdx.x; end = total; step = G; }
-  const int l4 = tc / 4;            // threads per tile row
+  const int l4 = tc / 4;            // threads per tile row (tc <= 1024: checked by the launcher)
   const int rpp = 256 / l4;         // rows per pass
   const int c4 = (threadIdx.x % l4) * 4, rr = threadIdx.x / l4;
   for (; tile < end; tile += step) {
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void store_pattern(float* out, int rows, int c
 }
 
 extern "C" int run_store_pattern(float* out, int rows, int cols, int64_t ld, int tr, int tc, int order, int nt_hint, int grid, void* stream) {
+  if (tc < 4 || tc > 1024 || tc % 4 || 256 % (tc / 4)) return -1;   // a tile row is written by 1..256 threads
   hipLaunchKernelGGL(store_pattern, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, rows, cols, ld, tr, tc, order, nt_hint);
   return (int)hipGetLastError();
 }
