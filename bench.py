@@ -35,6 +35,7 @@ import torch  # noqa: E402
 # v_mfma_f32_32x32x16_f16 per fp32-grade product, so its ceiling in ALGORITHMIC FLOP/s is a third of
 # the f16 MFMA peak; "f32" runs v_mfma_f32_32x32x2_f32 and is priced against the f32 matrix peak.
 F16_MATRIX_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
 F32_MATRIX_PEAK_TFLOPS = 157.3
 
 
@@ -150,6 +151,7 @@ def main():
     t_gather = time.perf_counter() - tg
     vdist.barrier(dev)
     elapsed = time.perf_counter() - t0
+    prof_hbm = hip.profile_end_hbm()
     prof = hip.profile_end()
     elapsed = vdist.max_over_ranks(elapsed, dev)
     if rank != 0:
@@ -201,6 +203,11 @@ def main():
             "share_of_step": d["ms"] / (1000.0 * t_compute),
             "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                  "launches": v["launches"]} for k, v in prof.items()},
+            # the HBM-bound stages of the path beside it: algorithmic bytes / HIP-event time
+            "hbm_kernels": {k: {"bound": "hbm", "achieved": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "launches": v["launches"], "avg_launch_us": 1000.0 * v["ms"] / v["launches"],
+                                "share_of_step": v["ms"] / (1000.0 * t_compute)} for k, v in prof_hbm.items()},
         }
 
     # -- CPU baseline (oracle) on a bounded sample of the same workload -------------------------

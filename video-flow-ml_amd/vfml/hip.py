@@ -131,17 +131,37 @@ def _dev(t, dtype=torch.float32):
 _PROFILE = None
 
 
+_PROFILE_HBM = None
+
+
 def profile_begin():
-    """Start recording (kernel variant, algorithmic FLOPs, start/end HIP events) per vfml_conv2d launch.
+    """Start recording (kernel variant, algorithmic FLOPs, start/end HIP events) per vfml_conv2d launch, and
+    (kernel, algorithmic bytes, events) per correlation lookup.
     Events are recorded on the stream the kernels are launched on (torch's current stream)."""
-    global _PROFILE
+    global _PROFILE, _PROFILE_HBM
     _PROFILE = []
+    _PROFILE_HBM = []
+
+
+def profile_end_hbm():
+    """{kernel: {"launches", "bytes", "ms"}} of the HBM-bound launches recorded since profile_begin()
+    (call before profile_end(), which stops the recording)."""
+    rec = _PROFILE_HBM or []
+    torch.cuda.synchronize()
+    out = {}
+    for name, nbytes, e0, e1 in rec:
+        d = out.setdefault(name, {"launches": 0, "bytes": 0.0, "ms": 0.0})
+        d["launches"] += 1
+        d["bytes"] += nbytes
+        d["ms"] += e0.elapsed_time(e1)
+    return out
 
 
 def profile_end():
     """Stop recording; returns {variant: {"launches", "flops", "ms"}} (synchronises)."""
-    global _PROFILE
+    global _PROFILE, _PROFILE_HBM
     rec, _PROFILE = _PROFILE or [], None
+    _PROFILE_HBM = None
     torch.cuda.synchronize()
     out = {}
     for variant, flops, e0, e1 in rec:
@@ -324,9 +344,21 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
         pyrs = [pyrs]
     nmaps, L = len(pyrs), len(pyrs[0])
     ptrs = (c_void_p * (nmaps * L))(*[p.data_ptr() for m in pyrs for p in m])
-    _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
-                                  nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
-                                  _ptr(_dev(out), out_off), ld_out, out_fmt, _stream()), "vfml_corr_lookup")
+
+    def launch():
+        _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
+                                      nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
+                                      _ptr(_dev(out), out_off), ld_out, out_fmt, _stream()), "vfml_corr_lookup")
+    if _PROFILE_HBM is None:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    # algorithmic bytes: per query and level the (2r+2)^2 integer-grid patch in, (2r+1)^2 samples out
+    q = nmaps * q_per_map
+    _PROFILE_HBM.append(("corr_lookup", q * L * ((2 * radius + 2) ** 2 + (2 * radius + 1) ** 2) * 4.0, e0, e1))
 
 
 def coords_init(coords1, n, h, w):

@@ -68,6 +68,7 @@ class MOFNetHIP(_Holder):
         self._packed_key = None
         self._packed_serial = 0
         self._ws = {}
+        self._pyr_free = []
         import collections
         self._feat_cache = collections.OrderedDict()
 
@@ -257,6 +258,21 @@ class MOFNetHIP(_Holder):
 
     def clear_feature_cache(self):
         self._feat_cache.clear()
+        self._pyr_free = []
+
+    def _pyramid_buffers(self, sizes, dev, limit):
+        """Level buffers for a new correlation pyramid (5.6 GB at 1080p).  When the pyramid cache is at its
+        limit the least recently used pyramid is retired FIRST and its buffers are handed to the new one:
+        in the steady state of a sliding job no field allocates (a 5.6 GB hipMalloc costs up to 150 ms, and
+        retiring only after the new allocation made the third field of every job pay for one)."""
+        while sum(1 for k in self._feat_cache if k[0] == "p") >= limit:
+            oldest = next(k for k in self._feat_cache if k[0] == "p")
+            self._pyr_free.append(self._feat_cache.pop(oldest))
+        for i, bufs in enumerate(self._pyr_free):
+            if [b.numel() for b in bufs] == sizes and bufs[0].device == dev:
+                return self._pyr_free.pop(i)
+        del self._pyr_free[:]          # other geometry: let the allocator have the memory back
+        return [torch.empty(n, device=dev) for n in sizes]
 
     def _cache_get(self, kind, key):
         ent = self._feat_cache.get((kind, key))
@@ -398,7 +414,7 @@ class MOFNetHIP(_Holder):
                         if pk is None:    # uncached call: reuse one workspace set per problem slot
                             pyr = [self._buf(f"pyr_{d}{c}_{l}", Pn * ldl[l], dev) for l in range(L)]
                         else:
-                            pyr = [torch.empty(Pn * ldl[l], device=dev) for l in range(L)]
+                            pyr = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=2 * (N - 2) + 2)
                         for l in range(L):
                             hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[l],
                                        ldl[l], out_scale=scale, in_fmt=AF)
