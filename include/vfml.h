@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 7
+#define VFML_ABI_VERSION 8
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -71,7 +71,19 @@ typedef struct vfml_conv_desc {
                                                        accumulator before bias/epilogue (a per-pixel bias:
                                                        the part of a convolution whose input does not
                                                        change between calls, computed once)             */
+  float* out_t; int32_t ld_out_t;                   /* optional (vfml_conv2d_split, GEMM form only): the
+                                                       TRANSPOSE of the result, out_t[co][pixel], row stride
+                                                       ld_out_t floats - the all-pairs correlation of frame
+                                                       pair (a, b) read the other way round is the volume of
+                                                       (b, a): one pass of MFMAs, two stores             */
+  int32_t flags;                                    /* VFML_CONV_* bits (vfml_conv2d_split)               */
 } vfml_conv_desc;
+
+/* flags: accumulate the two cross terms of the split product in the order (a_lo*b_hi, a_hi*b_lo) instead of
+ * (a_hi*b_lo, a_lo*b_hi).  out[q][s] of a call with operands (A, B) and out[s][q] of the call with operands
+ * (B, A) and this flag are then the same sequence of f32 additions, i.e. bit-identical - which makes a
+ * correlation volume computed directly equal to the one obtained as another call's out_t. */
+enum { VFML_CONV_SWAP_CROSS = 1 };
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
 

@@ -151,6 +151,44 @@ def test_wide_gemm_persistent_path(gpu, bias, epi):
     assert (got[:, S:] == 7.0).all()          # nothing written past cout
 
 
+def test_wide_gemm_with_transposed_second_output(gpu):
+    """out[q][s] = <f1[q], f2[s]>/16 and, from the same pass, out_t[s][q] (the correlation volume of the frame
+    pair read the other way round): ragged edge tiles in both directions, nothing written outside.  With each
+    operand's split-row and split-plane forms cut from the same scaled copy (as the engine does), the reverse
+    problem computed directly with VFML_CONV_SWAP_CROSS is bit-identical to the transposed output."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(23)
+    P, S, D = 1300, 1412, 256
+    f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
+    ld, ldt = (S + 31) // 32 * 32, (P + 31) // 32 * 32
+    SC = 16.0                                                       # both operands carry x16, undone by out_scale
+
+    def rows(f):
+        t = torch.empty(f.numel(), device=gpu)
+        hip.to_s16((f * SC).cuda().reshape(-1), f.shape[0], D, D, t, D)
+        return t
+
+    def planes(f):
+        return hip.SplitWeight(f.shape[0], D, torch.device("cuda")).fill(f.cuda().reshape(-1).contiguous(), scale=SC)
+
+    out = torch.full((P * ld,), 7.0, device=gpu)
+    out_t = torch.full((S * ldt,), 9.0, device=gpu)
+    hip.conv2d(rows(f1), D, D, 1, 1, P, planes(f2), None, S, 1, 1, out, ld, out_scale=1.0 / 16.0 / SC,
+               in_fmt=hip.FMT_S16, out_t=out_t, ld_out_t=ldt)
+    ref = (f1.double() @ f2.double().t() / 16.0).float()
+    got, got_t = out.view(P, ld).cpu(), out_t.view(S, ldt).cpu()
+    assert rel_err(got[:, :S], ref) < CONV_TOL["f16x3"]
+    assert torch.equal(got_t[:, :P], got[:, :S].t())            # the same accumulators, stored twice
+    assert (got[:, S:] == 7.0).all() and (got_t[:, P:] == 9.0).all()
+    rev = torch.zeros(S * ldt, device=gpu)
+    hip.conv2d(rows(f2), D, D, 1, 1, S, planes(f1), None, P, 1, 1, rev, ldt, out_scale=1.0 / 16.0 / SC,
+               in_fmt=hip.FMT_S16, swap_cross=True)
+    assert torch.equal(rev.view(S, ldt).cpu()[:, :P], got_t[:, :P])
+    with pytest.raises(RuntimeError, match="out_t"):              # only the GEMM form has it
+        hip.conv2d(rows(f1), D, D, 1, 1, P, planes(f2[:64]), None, 64, 1, 1, out, ld,
+                   in_fmt=hip.FMT_S16, out_t=out_t, ld_out_t=ldt)
+
+
 def test_gemm_rows_of_a_source_larger_than_one_descriptor(gpu):
     """1x1 over one split-row source whose rows span 2.2 GB (> the 2 GiB a buffer descriptor covers): the
     LDS-DMA kernel rebases its descriptor per tile.  (MemFlow's attention read-out: 4.2 GB of attention rows.)"""

@@ -76,6 +76,8 @@ struct SplitArgs {
   // one row stride): per K step the tap / channel offset is one scalar
   int fastk, abias, src1_delta;
   int tilebase;   // 1x1 over one source: the source descriptor starts at the tile's first row (sources > 2 GiB)
+  float* out_t; int ld_out_t;   // GEMM form: transposed second output (or null)
+  int cswap;                    // VFML_CONV_SWAP_CROSS
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -523,7 +525,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 // straight to global, the next tile's first loads and this tile's stores overlap the neighbours' MFMAs.
 // FASTK: the uniform-step loader (SplitArgs::fastk) as a compile-time choice - with both loaders in one
 // body hipcc stops unrolling the MFMA loops of the larger tiles and the accumulators go to scratch.
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK>
+// CSWAP: VFML_CONV_SWAP_CROSS as a compile-time choice (GEMM form only; a runtime branch in the MFMA loop spills).
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
@@ -760,8 +763,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (CSWAP) {         // VFML_CONV_SWAP_CROSS (correlation GEMMs of the backward problems)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          }
 #ifndef VFML_ISSUE_GROUPS
 #define VFML_ISSUE_GROUPS (TM * TN)      // the first half of the step: the second half covers the pieces' L2 latency
 #endif
@@ -783,13 +791,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   const int nk = (a.Kp / BK + 1) & ~1;
   constexpr int NSTORE = TM * TN * 4;                    // direct epilogue: 16-byte stores per thread, all issued
   constexpr int RELAXED = NSTORE < 63 ? NSTORE : 63;     // vmcnt that still covers the older DMAs
+  constexpr int NSTORE_T = NSTORE + TM * TN * 4;         // with the transposed second output
+  constexpr int RELAXED_T = NSTORE_T < 63 ? NSTORE_T : 63;
   bool stores_behind = false;   // PERSIST: the previous tile's stores are still in flight behind this tile's first DMAs
   auto step_pair = [&](int kt, bool last, int next) {
     // A tile's first wait must not drain the previous tile's stores: vmcnt counts in issue order and the
     // first step's DMAs were issued BEFORE them, so leaving min(63, NSTORE) operations outstanding still
     // waits for every DMA (the stores then have one whole K step to finish before the next vmcnt(0)).
     if (PERSIST && stores_behind) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAXED) : "memory");
+      if (a.out_t) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAXED_T) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAXED) : "memory");
       stores_behind = false;
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -890,6 +901,36 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, gcol < cols_valid ? lbase + roff : OOB, 0,
                                                  VFML_STORE_AUX);
         }
+        if constexpr (PERSIST && TN == 2 && FASTK) if (a.out_t) {   // (the general-loader instantiation would spill)
+          // The transposed copy, out_t[column][row]: the block goes through the same 8 KiB as [column][row]
+          // with the row index rotated by (column >> 1) - the 32 lanes of a store group (one row, 32
+          // columns) then hit 32 different banks - and leaves as 16-byte runs along the rows: a store
+          // instruction covers 8 rows of out_t x 128 contiguous bytes.
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = (e & 3) + 8 * (e >> 2) + 4 * half, col = j * 32 + r;
+              ws[col * 32 + ((row + (col >> 1)) & 31)] = acc[i][j][e];
+            }
+          const int rows_t = cols_valid, cols_t = rows_valid;      // extent of the transposed tile
+          float* tbase_t = a.out_t + (int64_t)cur_n0 * a.ld_out_t + cur_m0;
+          const __amdgpu_buffer_rsrc_t rt =
+              __builtin_amdgcn_make_buffer_rsrc(tbase_t, 0, ((rows_t - 1) * a.ld_out_t + cols_t) * 4, 0x00020000);
+          const int g = lane >> 3, cl = lane & 7;
+#pragma unroll
+          for (int pp = 0; pp < 8; ++pp) {
+            const int c = pp * 8 + cl;                              // column of the wave's block = row of out_t
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ws[c * 32 + ((4 * g + k + (c >> 1)) & 31)] * a.w_inv * a.out_scale;
+            const int q0 = wm * (32 * TM) + i * 32 + 4 * g;         // first of the four pixels (columns of out_t)
+            const int trow = wn * WC + c;
+            const bool ok = trow < rows_t && q0 < cols_t;           // M % 4 == 0 (host check): a quad is whole
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt,
+                                                   ok ? (trow * a.ld_out_t + q0) * 4 : OOB, 0, VFML_STORE_AUX);
+          }
+        }
       }
       stores_behind = true;
     } else {
@@ -914,7 +955,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK>
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
   constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
@@ -925,7 +966,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   a.ntiles = (a.cout + TBN - 1) / TBN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -937,14 +978,16 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.mtiles * a.ntiles;
   const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
   const int grid = (int)(PERSIST && total > slots ? slots : total);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
 template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
-  if (a.direct)     // (128 x 128: the one persistent tile shape that does not spill)
+  if (a.direct) {   // (128 x 128: the one persistent tile shape that does not spill)
+    if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
+  }
   if constexpr (WM * WN == 4 && TM * TN >= 2) {   // the shapes the dispatcher picks by itself
     if (a.fastk) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
   }
@@ -1114,6 +1157,9 @@ extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, flo
 extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
                                  int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
+  VFML_REQUIRE((d->flags & ~VFML_CONV_SWAP_CROSS) == 0, "vfml_conv2d_split: unknown flag bits");
+  VFML_REQUIRE(in_fmt == VFML_FMT_S16 || (d->flags == 0 && d->out_t == nullptr),
+               "vfml_conv2d_split: out_t / flags need split-row sources");
   VFML_REQUIRE(k_order == VFML_KORDER_TAP || (k_order == VFML_KORDER_CBLOCK && in_fmt == VFML_FMT_S16),
                "vfml_conv2d_split: bad k_order (channel-block order needs split-row sources)");
   VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
@@ -1175,7 +1221,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_ADD_AUX, "vfml_conv2d_split: bad epilogue");
 
   SplitArgs a;
-  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0;
+  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;
@@ -1249,6 +1295,18 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
       a.direct = (d->epilogue == VFML_EPI_NONE || d->epilogue == VFML_EPI_RELU) && !d->addend && out_fmt == VFML_FMT_F32 &&
                  d->cout >= direct_min && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&
                  (!d->bias || vfml_aligned16(d->bias));
+      if (d->flags & VFML_CONV_SWAP_CROSS) {
+        VFML_REQUIRE(a.direct && a.fastk, "vfml_conv2d_split: VFML_CONV_SWAP_CROSS is implemented by the GEMM form only "
+                                          "(1x1 over whole 32-channel blocks, plain f32 out, cout >= 1024, cout %% 4 == 0)");
+        a.cswap = 1;
+      }
+      if (d->out_t) {
+        VFML_REQUIRE(a.direct && a.fastk && a.pointwise && !d->bias && d->epilogue == VFML_EPI_NONE && a.M % 4 == 0 &&
+                     d->ld_out_t % 4 == 0 && d->ld_out_t >= a.M && vfml_aligned16(d->out_t),
+                     "vfml_conv2d_split: out_t needs the GEMM form (1x1 over whole 32-channel blocks, plain f32 out, cout >= 1024, cout %% 4 == 0), no bias / "
+                     "epilogue, pixels %% 4 == 0, ld_out_t %% 4 == 0 and >= pixels, 16-byte alignment");
+        a.out_t = d->out_t; a.ld_out_t = d->ld_out_t;
+      }
       static const char* tile_env = getenv("VFML_DMA_TILE");   // experiments: "TM,TN,WM,WN"
       int cfg = d->cout > 32 ? 2122 : 1141;
       if (d->cout > 64) {

@@ -19,6 +19,7 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 KORDER_TAP, KORDER_CBLOCK = 0, 1   # K-axis order of split weight planes (include/vfml.h)
+CONV_SWAP_CROSS = 1                 # vfml_conv_desc.flags
 
 
 class ConvDesc(ctypes.Structure):
@@ -35,6 +36,8 @@ class ConvDesc(ctypes.Structure):
         ("aux0", c_void_p), ("ld_aux0", c_int32),
         ("aux1", c_void_p), ("ld_aux1", c_int32),
         ("addend", c_void_p), ("ld_addend", c_int32),
+        ("out_t", c_void_p), ("ld_out_t", c_int32),
+        ("flags", c_int32),
     ]
 
 
@@ -90,7 +93,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 7:
+    if L.vfml_abi_version() != 8:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -243,7 +246,8 @@ class SplitWeight:
 def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, stride=1, pad_h=0, pad_w=0,
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
-           in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0):
+           in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
+           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers)."""
     d = ConvDesc()
@@ -259,6 +263,8 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.aux0, d.ld_aux0 = (_ptr(_dev(aux0), aux0_off) if aux0 is not None else None), ld_aux0
     d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
     d.addend, d.ld_addend = (_ptr(_dev(addend), addend_off) if addend is not None else None), ld_addend
+    d.out_t, d.ld_out_t = (_ptr(_dev(out_t), out_t_off) if out_t is not None else None), ld_out_t
+    d.flags = CONV_SWAP_CROSS if swap_cross else 0
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
         def launch():

@@ -170,7 +170,7 @@ class MemFlowNetHIP(MOFNetHIP):
             pyr = [self._buf(f"mpyr_{l}", Pn * ldl[l], dev) for l in range(L)]
             for l in range(L):
                 hip.conv2d(feats[0][0], D, D, 1, 1, Pn, feats[1][1][l], None, Sl[l], 1, 1, pyr[l], ldl[l],
-                           out_scale=1.0 / float(D) ** 0.5, in_fmt=AF)
+                           out_scale=1.0 / float(D) ** 0.5 / self.FMAP_ROW_SCALE, in_fmt=AF)   # query rows carry x16
 
             GLD, Z, RH, HH, INP, MF, MT = 768, 0, 128, 256, 384, 512, 640
             G = self._buf("gru_state", Pn * GLD, dev)

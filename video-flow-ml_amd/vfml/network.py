@@ -21,6 +21,8 @@ Pipeline per call (names from SURVEY.md §2b):
         flow head                          vfml_conv2d, vfml_coords_update
   mask head (last iteration only) + K8 8x convex upsampling   vfml_conv2d, vfml_convex_upsample
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -255,6 +257,7 @@ class MOFNetHIP(_Holder):
 
     # ------------------------------------------------------------------ per-frame encoder cache
     FEATURE_CACHE_FRAMES = 12
+    FMAP_ROW_SCALE = 16.0       # power of two: exact; undone by the correlation GEMM's out_scale
 
     def clear_feature_cache(self):
         self._feat_cache.clear()
@@ -317,9 +320,13 @@ class MOFNetHIP(_Holder):
                     # features are O(1): x16 keeps the lo halves of the split normal
                     tg.append(hip.SplitWeight(Sl[l], D, dev).fill(f, scale=16.0) if split else f)
                 fm = fmap[i * Pn * D:(i + 1) * Pn * D]
-                if split:   # the GEMM's A operand in split rows, made once per frame
+                if split:
+                    # the GEMM's A operand in split rows, made once per frame - of the SAME x16 copy the target
+                    # planes are split from, so that a frame's hi / lo halves are the same numbers on either
+                    # side of a correlation GEMM (then <a, b> and <b, a> are the same products, and with
+                    # VFML_CONV_SWAP_CROSS the same sums: a volume and its transpose are bit-identical)
                     fm16 = torch.empty(Pn * D, device=dev)
-                    hip.to_s16(fm, Pn, D, D, fm16, D)
+                    hip.to_s16(fm * self.FMAP_ROW_SCALE, Pn, D, D, fm16, D)
                     fm = fm16
                 ent = (fm, tg)
                 out[j] = ent
@@ -405,6 +412,8 @@ class MOFNetHIP(_Holder):
             # A pyramid depends on its two frames only, so with frame keys it is kept across windows:
             # consecutive sliding windows share 2(N-3) of their 2(N-2) problems.
             scale = 1.0 / float(D) ** 0.5
+            if AF == hip.FMT_S16:
+                scale /= self.FMAP_ROW_SCALE       # the split-row query features carry a factor 16
             pyrs = {"f": [], "b": []}
             for c in range(1, N - 1):
                 for d, tgt in (("f", c + 1), ("b", c - 1)):
@@ -414,12 +423,34 @@ class MOFNetHIP(_Holder):
                         if pk is None:    # uncached call: reuse one workspace set per problem slot
                             pyr = [self._buf(f"pyr_{d}{c}_{l}", Pn * ldl[l], dev) for l in range(L)]
                         else:
-                            pyr = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=2 * (N - 2) + 2)
+                            # (registered before it is filled: same stream, and the next allocation then sees
+                            # the right count and retires a stale pyramid instead of asking the allocator)
+                            lim = 2 * (N - 2) + 2
+                            pyr = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=lim)
+                            self._cache_put("p", pk, pyr, limit=lim)
+                        # Level 0 of the reverse problem (tgt -> c) is the transpose of this one's: when it is
+                        # going to be needed (tgt is, or next field becomes, a centre frame: the "f" problems of
+                        # a forward-sliding job) the same pass of MFMAs stores it too (vfml_conv_desc.out_t), and
+                        # only its three pooled levels are separate GEMMs.  In the steady state a field then
+                        # builds its two new pyramids with one 32400 x 32400 GEMM instead of two.
+                        # (a backward problem's level 0 computed directly uses VFML_CONV_SWAP_CROSS, the addition
+                        # order of a transposed forward volume: both routes give the same bits)
+                        rk = ("p", keys[tgt], keys[c]) if pk is not None else None
+                        gemm_form = AF == hip.FMT_S16 and Pn % 4 == 0 and Sl[0] >= 1024 and not self.tri_frame
+                        dual = (rk is not None and d == "f" and gemm_form and ("p", rk) not in self._feat_cache
+                                and not os.environ.get("VFML_NO_DUAL"))      # (A/B switch; results are identical)
+                        rev = None
+                        if dual:
+                            rev = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=lim)
+                            self._cache_put("p", rk, rev, limit=lim)
                         for l in range(L):
                             hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[l],
-                                       ldl[l], out_scale=scale, in_fmt=AF)
-                        if pk is not None:
-                            self._cache_put("p", pk, pyr, limit=2 * (N - 2) + 2)
+                                       ldl[l], out_scale=scale, in_fmt=AF, swap_cross=(d == "b" and l == 0 and gemm_form),
+                                       out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0)
+                        if dual:
+                            for l in range(1, L):
+                                hip.conv2d(feats[tgt][0], D, D, 1, 1, Pn, feats[c][1][l], None, Sl[l], 1, 1, rev[l],
+                                           ldl[l], out_scale=scale, in_fmt=AF)
                     pyrs[d].append(pyr)
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
