@@ -226,9 +226,13 @@ def test_to_s16_roundtrip(gpu):
 
 
 @pytest.mark.parametrize("cblock", [False, True])
-@pytest.mark.parametrize("cin,cout,kh,kw", [(64, 128, 3, 3), (256, 124, 3, 3), (128, 64, 1, 1), (512, 256, 1, 5),
-                                            (72, 192, 3, 3), (256, 4, 3, 3), (40, 36, 5, 1), (656, 256, 1, 1)])
-def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw, cblock):
+@pytest.mark.parametrize("cin,cout,kh,kw,stride", [(64, 128, 3, 3, 1), (256, 124, 3, 3, 1), (128, 64, 1, 1, 1),
+                                                   (512, 256, 1, 5, 1), (72, 192, 3, 3, 1), (256, 4, 3, 3, 1),
+                                                   (40, 36, 5, 1, 1), (656, 256, 1, 1, 1),
+                                                   (64, 96, 3, 3, 2),       # strided, uniform-step loader
+                                                   (32, 128, 5, 5, 1),      # 25 taps: tap masks beyond 9 bits
+                                                   (96, 128, 1, 1, 2)])     # strided 1x1 is not the GEMM-rows case
+def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw, stride, cblock):
     """Split-row (S16) activations in, split-row activations out == the f32-in/f32-out result, with
     the weights in tap order and in channel-block order (incl. channel counts that are not multiples
     of 32 and every tile width of the LDS-DMA kernel)."""
@@ -239,17 +243,52 @@ def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw, cblock):
     x = torch.randn(n, cin, H, W, generator=g)
     wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
     b = torch.randn(cout, generator=g)
-    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=(kh // 2, kw // 2))).float()
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=(kh // 2, kw // 2))).float()
+    ho, wo = ref.shape[-2:]
     w = as_weight(pack_conv_weight(wt, cblock=cblock), cout, "f16x3", order=int(cblock))
     x16 = torch.empty(n * H * W * cin, device=gpu)
     hip.to_s16(nhwc(x), n * H * W, cin, cin, x16, cin)
     ldo = (cout + 7) // 8 * 8 + 8
-    out = torch.zeros(n * H * W * ldo, device=gpu)
-    hip.conv2d(x16, cin, cin, n, H, W, w, b.cuda(), cout, kh, kw, out, ldo, pad_h=kh // 2, pad_w=kw // 2,
+    out = torch.zeros(n * ho * wo * ldo, device=gpu)
+    hip.conv2d(x16, cin, cin, n, H, W, w, b.cuda(), cout, kh, kw, out, ldo, stride=stride, pad_h=kh // 2, pad_w=kw // 2,
                epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16)
-    got = s16_decode(out, n * H * W, ldo, ldo)
+    got = s16_decode(out, n * ho * wo, ldo, ldo)
     assert (got[:, (cout + 3) // 4 * 4:] == 0).all()            # nothing written past cout
-    got = got[:, :cout].view(n, H, W, cout).permute(0, 3, 1, 2)
+    got = got[:, :cout].view(n, ho, wo, cout).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < CONV_TOL["f16x3"]
+
+
+@pytest.mark.parametrize("same_ld", [True, False])
+@pytest.mark.parametrize("cblock", [False, True])
+def test_two_split_row_sources_odd_step_count(gpu, cblock, same_ld):
+    """cat([a, b]) from two split-row sources, 3x1 taps over 32 + 64 channels = 9 K steps (an odd count: the
+    kernel's rounding-up step must add nothing), sources as slices of one buffer (one row stride: the
+    uniform-step loader) or with different row strides (the general loader)."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(15)
+    n, H, W, ca, cb, cout = 2, 9, 14, 32, 64, 136
+    a, b = torch.randn(n, ca, H, W, generator=g), torch.randn(n, cb, H, W, generator=g)
+    wt = torch.randn(cout, ca + cb, 3, 1, generator=g) / math.sqrt((ca + cb) * 3)
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(torch.cat([a, b], 1).double(), wt.double(), bias.double(), padding=(1, 0))).float()
+    P = n * H * W
+    lda, ldb = (128, 128) if same_ld else (32, 72)
+    if same_ld:
+        buf = torch.zeros(P * 128, device=gpu)
+        hip.to_s16(nhwc(a), P, ca, ca, buf, 128, dst_off=8)
+        hip.to_s16(nhwc(b), P, cb, cb, buf, 128, dst_off=48)
+        srca, offa, srcb, offb = buf, 8, buf, 48
+    else:
+        buf = torch.zeros(P * (32 + 72), device=gpu)
+        hip.to_s16(nhwc(a), P, ca, ca, buf, 32)
+        hip.to_s16(nhwc(b), P, cb, cb, buf, 72, dst_off=P * 32)
+        srca, offa, srcb, offb = buf, 0, buf, P * 32
+    w = as_weight(pack_conv_weight(wt, cblock=cblock), cout, "f16x3", order=int(cblock))
+    out = torch.zeros(P * cout, device=gpu)
+    hip.conv2d(srca, ca, lda, n, H, W, w, bias.cuda(), cout, 3, 1, out, cout, in0_off=offa, in1=srcb, c1=cb, ld1=ldb,
+               in1_off=offb, pad_h=1, epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16)
+    got = out.view(n, H, W, cout).permute(0, 3, 1, 2).cpu()
     assert rel_err(got, ref) < CONV_TOL["f16x3"]
 
 

@@ -664,10 +664,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       const int cl = scb < a.c0 ? scb : scb - a.c0;
       soffA = ((sky * a.W + skx) * a.ld0 + cl) * 4 + (scb < a.c0 ? 0 : a.src1_delta);
       const unsigned stap = sky * a.kw + skx;
+      // the rounding-up step of an odd step count lies past the last channel block: zeros, like every K tail
+      const int past = scb >= a.ctot ? (int)0x80000000 : 0;
 #pragma unroll
       for (int j = 0; j < AP; ++j) {
         const int bad = __builtin_amdgcn_sbfe((int)(unsigned)tapok[j], stap, 1u);   // -1: tap outside the image (or row past M)
-        va[j] = (bad & (int)0x80000000) | rp0[j];
+        va[j] = (bad & (int)0x80000000) | past | rp0[j];
       }
       if (++skx == a.kw) {
         skx = 0;
