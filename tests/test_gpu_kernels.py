@@ -189,6 +189,31 @@ def test_wide_gemm_with_transposed_second_output(gpu):
                    in_fmt=hip.FMT_S16, out_t=out_t, ld_out_t=ldt)
 
 
+@pytest.mark.parametrize("P,S", [(128, 1024), (516, 1028), (3000, 1500), (308, 5000), (4100, 1024), (8, 1152)])
+def test_gemm_form_sizes(gpu, P, S):
+    """The persistent GEMM form over tile counts below, at and above the resident slots' granularity (1, 5, 8k+r,
+    ... tiles), with and without the transposed output."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(24)
+    D = 64
+    f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
+    ref = (f1.double() @ f2.double().t()).float()
+    x16 = torch.empty(P * D, device=gpu)
+    hip.to_s16(f1.cuda().reshape(-1), P, D, D, x16, D)
+    w = as_weight(f2.reshape(-1), S, "f16x3")
+    ld, ldt = (S + 31) // 32 * 32, (P + 31) // 32 * 32
+    for dual in (False, True):
+        out = torch.full((P * ld,), 3.0, device=gpu)
+        out_t = torch.full((S * ldt,), 4.0, device=gpu) if dual else None
+        hip.conv2d(x16, D, D, 1, 1, P, w, None, S, 1, 1, out, ld, in_fmt=hip.FMT_S16, out_t=out_t, ld_out_t=ldt if dual else 0)
+        got = out.view(P, ld).cpu()
+        assert rel_err(got[:, :S], ref) < CONV_TOL["f16x3"], (P, S, dual)
+        assert (got[:, S:] == 3.0).all()
+        if dual:
+            gt = out_t.view(S, ldt).cpu()
+            assert torch.equal(gt[:, :P], got[:, :S].t()) and (gt[:, P:] == 4.0).all()
+
+
 def test_gemm_rows_of_a_source_larger_than_one_descriptor(gpu):
     """1x1 over one split-row source whose rows span 2.2 GB (> the 2 GiB a buffer descriptor covers): the
     LDS-DMA kernel rebases its descriptor per tile.  (MemFlow's attention read-out: 4.2 GB of attention rows.)"""
@@ -256,6 +281,44 @@ def test_conv2d_split_rows_in_and_out(gpu, cin, cout, kh, kw, stride, cblock):
     assert (got[:, (cout + 3) // 4 * 4:] == 0).all()            # nothing written past cout
     got = got[:, :cout].view(n, ho, wo, cout).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < CONV_TOL["f16x3"]
+
+
+def test_split_row_conv_random_shapes(gpu):
+    """40 seeded random split-row convolutions (channels, taps, stride, padding, image size, K order, epilogue,
+    ragged cout and pixel counts) against float64 PyTorch: sweeps the LDS-DMA kernel's loaders, tile widths
+    and edge handling beyond the shapes the networks use."""
+    import random
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    rnd = random.Random(20250829)
+    g = torch.Generator().manual_seed(16)
+    for case in range(40):
+        cin = rnd.choice([32, 40, 64, 72, 96, 128, 160])
+        cout = rnd.choice([4, 20, 33, 64, 100, 128, 136, 192, 260])
+        kh, kw = rnd.choice([(1, 1), (3, 3), (1, 5), (5, 1), (3, 1), (5, 5), (1, 3)])
+        stride = rnd.choice([1, 1, 1, 2])
+        ph, pw = rnd.choice([0, kh // 2]), rnd.choice([0, kw // 2])
+        n, H, W = rnd.choice([1, 2, 3]), rnd.randint(kh + 2, 19), rnd.randint(kw + 2, 23)
+        cblock = rnd.random() < 0.6
+        relu = rnd.random() < 0.5
+        x = torch.randn(n, cin, H, W, generator=g)
+        wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+        b = torch.randn(cout, generator=g)
+        ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=(ph, pw))
+        ref = (F.relu(ref) if relu else ref).float()
+        ho, wo = ref.shape[-2:]
+        ld = cin + rnd.choice([0, 8, 24])
+        x16 = torch.zeros(n * H * W * ld, device=gpu)
+        hip.to_s16(nhwc(x), n * H * W, cin, cin, x16, ld)
+        w = as_weight(pack_conv_weight(wt, cblock=cblock), cout, "f16x3", order=int(cblock))
+        ldo = cout + rnd.choice([0, 3, 8])
+        out = torch.full((n * ho * wo * ldo,), 5.0, device=gpu)
+        hip.conv2d(x16, cin, ld, n, H, W, w, b.cuda(), cout, kh, kw, out, ldo, stride=stride, pad_h=ph, pad_w=pw,
+                   epilogue=hip.EPI_RELU if relu else hip.EPI_NONE, in_fmt=hip.FMT_S16)
+        got = out.view(n, ho, wo, ldo).cpu()
+        tag = f"case {case}: cin {cin} cout {cout} {kh}x{kw} s{stride} p{ph},{pw} n{n} {H}x{W} ld{ld} ldo{ldo} cblock {cblock}"
+        assert (got[..., cout:] == 5.0).all(), tag
+        assert rel_err(got[..., :cout].permute(0, 3, 1, 2), ref) < CONV_TOL["f16x3"], tag
 
 
 @pytest.mark.parametrize("same_ld", [True, False])
