@@ -175,7 +175,8 @@ def profile_end():
     return out
 
 
-def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False):
+def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False,
+                 cswap=False):
     """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
     the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
     split kernel for cout > 64 is not modelled)."""
@@ -186,11 +187,11 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
     if dma:     # split-f16, LDS-DMA staged
         fk = "true" if fastk else "false"       # uniform-step loader (SplitArgs::fastk)
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
-            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}>"          # persistent GEMM form
+            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}>"   # persistent GEMM form
         if cout <= 32:
-            return "conv_gemm_dma_kernel<1, 1, 4, 1, false, false>"
+            return "conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false>"
         if cout <= 64:
-            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}>"
+            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false>"
         def cost(tbm, tbn, mf, eff):
             tiles = -(-m // tbm) * -(-cout // tbn)
             return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
@@ -201,7 +202,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         for c, name in cands[1:]:
             if c < best:
                 best, t = c, name
-        return f"conv_gemm_dma_kernel<{t}, false, {fk}>"
+        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
 
@@ -294,7 +295,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
              and c0 % 32 == 0 and ctot % 32 == 0 and kh * kw <= 32 and not os.environ.get("VFML_NO_FASTK")
              and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
-                                  weight.order if is_split else KORDER_TAP, plain, fastk),
+                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
