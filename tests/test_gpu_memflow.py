@@ -126,3 +126,30 @@ def test_memflow_host_path_matches_oracle(gpu, tmp_path, monkeypatch):
     epe = np.sqrt(((got - ref) ** 2).sum(-1))
     assert epe.mean() < EPE_TOL, epe.mean()
     assert np.array_equal(eng.compute_optical_flow_tiled(frames, 2), got)      # MemFlow never tiles
+
+
+def test_memflow_resident_loop_reuses_encoder_outputs_exactly(gpu, tmp_path, monkeypatch):
+    """The resident job loop (uint8 clip in HBM, frame ids as cache keys: the "current" frame of one field is
+    the "previous" frame of the next and is encoded once) gives bit-identical fields to the host-array call,
+    which encodes both frames of every pair; padded size, so the pad is part of the cached input."""
+    import contextlib
+    import io
+    import os
+    import numpy as np
+    from processing.memflow_inference import MemFlowInference
+    from vfml.memflow_net import memflow_cfg, seeded_memflow_state_dict
+    from vfml.synth import synthetic_clip
+    os.makedirs(tmp_path / "MemFlow_ckpt")
+    torch.save(seeded_memflow_state_dict(memflow_cfg(), 0), tmp_path / "MemFlow_ckpt" / "MemFlowNet_sintel.pth")
+    monkeypatch.chdir(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = MemFlowInference("cuda", sequence_length=3)
+        eng.load_model()
+    proc = eng.get_processor()
+    frames = synthetic_clip(6, 132, 200)
+    clip = proc.upload_clip(frames)
+    net = proc.core_engine.model
+    for i in range(6):
+        a = proc.compute_optical_flow_resident(clip, i).cpu().numpy()
+        assert np.array_equal(a, eng.compute_optical_flow(frames, i)), i
+    assert sum(1 for k in net._feat_cache if k[0] == "f") >= 2          # the cache is in use

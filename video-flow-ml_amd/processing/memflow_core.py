@@ -80,26 +80,37 @@ class MemFlowCore:
             print(f"Warning: Tensor device ({have}) differs from model device ({want})")
 
     @staticmethod
-    def normalise(frames):
-        """Value-range heuristic of the reference's inference script (:81-85)."""
+    def normalise(frames, return_mode=False):
+        """Value-range heuristic of the reference's inference script (:81-85); with return_mode also which of
+        its three branches was taken (part of a frame's cache identity: the same pixels normalised
+        differently are different network inputs)."""
         mx = frames.max().item()
         if mx > 2.0:
-            return 2 * (frames / 255.0) - 1.0
-        if mx > 1.0:
-            return 2 * frames - 1.0
-        return frames
+            out, mode = 2 * (frames / 255.0) - 1.0, 0
+        elif mx > 1.0:
+            out, mode = 2 * frames - 1.0, 1
+        else:
+            out, mode = frames, 2
+        return (out, mode) if return_mode else out
 
-    def compute_flow_from_tensor(self, frames_tensor: torch.Tensor, keep_on_device: bool = False) -> torch.Tensor:
+    def compute_flow_from_tensor(self, frames_tensor: torch.Tensor, keep_on_device: bool = False,
+                                 frame_keys=None) -> torch.Tensor:
         """[1,T,3,H,W] (0..255, 0..1 or -1..1 floats, any device) -> flow [2,H,W] on the CPU
-        (keep_on_device=True, an extension, skips the download for callers that gather on the GPU)."""
+        (keep_on_device=True, an extension, skips the download for callers that gather on the GPU;
+        frame_keys, an extension: one hashable id per frame of the window - the engine then keeps each
+        frame's feature encoder output for the call in which that frame is the previous one)."""
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
         self.validate_input_tensor(frames_tensor)
         with torch.no_grad():
-            x = self.normalise(frames_tensor.to(self.device).float())
+            x, mode = self.normalise(frames_tensor.to(self.device).float(), return_mode=True)
             padder = InputPadder(x.shape)
             x = padder.pad(x)
-            _, flow = self.model(x[:, -2:])
+            if frame_keys is not None and hasattr(self.model, "_frame_features"):
+                keys = [(k, mode, tuple(x.shape[-2:])) for k in list(frame_keys)[-2:]]
+                _, flow = self.model(x[:, -2:], None, frame_keys=keys)
+            else:
+                _, flow = self.model(x[:, -2:])
             flow = padder.unpad(flow[0])
             return flow if keep_on_device else flow.cpu()
 

@@ -77,8 +77,10 @@ class MemFlowProcessor:
         """uint8 clip [F,H,W,3] on the device -> flow [H,W,2] on the device (tile is ignored: MemFlow
         works on full frames, reference :190-247)."""
         from vfml.network import take_frames
-        x = take_frames(clip, self.window_indices(frame_idx)).permute(0, 3, 1, 2).float().unsqueeze(0)
-        return self.core_engine.compute_flow_from_tensor(x, keep_on_device=True).permute(1, 2, 0)
+        ids = self.window_indices(frame_idx)
+        x = take_frames(clip, ids).permute(0, 3, 1, 2).float().unsqueeze(0)
+        keys = [(clip.data_ptr(), clip._version, i) for i in ids]      # same clip, same frame = same pixels
+        return self.core_engine.compute_flow_from_tensor(x, keep_on_device=True, frame_keys=keys).permute(1, 2, 0)
 
     def compute_optical_flow_with_progress(self, frames, frame_idx, tile_pbar=None) -> np.ndarray:
         if tile_pbar is not None:

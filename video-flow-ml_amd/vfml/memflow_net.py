@@ -130,9 +130,12 @@ class MemFlowNetHIP(MOFNetHIP):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, pair, data=None):
+    def forward(self, pair, data=None, frame_keys=None):
         """pair: float [1, 2, 3, H, W] in [-1, 1] on the GPU (previous, current).
-        Returns (flow_low [1,2,h,w], flow [1,2,H,W]) like InferenceCore.step(..., end=True)."""
+        Returns (flow_low [1,2,h,w], flow [1,2,H,W]) like InferenceCore.step(..., end=True).
+        frame_keys: optional pair of hashable ids of the two frames (same id = same normalised pixels): the
+        feature encoder output of a frame is then kept, so a frame that is "current" in one call and
+        "previous" in the next is encoded once (results bit-identical)."""
         if not isinstance(pair, torch.Tensor) or not pair.is_cuda:
             raise RuntimeError("MemFlowNetHIP runs on an MI355X (HIP) device only; got "
                                f"{getattr(pair, 'device', type(pair))}. There is no CPU fallback in the shipped engine.")
@@ -165,7 +168,12 @@ class MemFlowNetHIP(MOFNetHIP):
                 wl.append(wl[-1] // 2)
             Sl = [hl[l] * wl[l] for l in range(L)]
             ldl = [(s + 31) // 32 * 32 for s in Sl]
-            feats = self._frame_features(src, [0, 1], None, H, W, P, dev, L, hl, wl, Sl)
+            keys = None
+            if frame_keys is not None:
+                if len(frame_keys) != 2:
+                    raise ValueError("frame_keys must hold one id per frame of the pair")
+                keys = [("memflow", k, H, W, L, self._precision(), self._packed_serial) for k in frame_keys]
+            feats = self._frame_features(src, [0, 1], keys, H, W, P, dev, L, hl, wl, Sl)
             ctx = self._frame_context_plain(src, H, W, P, dev, Pn, AF)
             pyr = [self._buf(f"mpyr_{l}", Pn * ldl[l], dev) for l in range(L)]
             for l in range(L):
