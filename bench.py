@@ -113,6 +113,12 @@ def main():
         """Flow fields of frames `idxs` into dst[k] ([H,W,2] each, on the device); in --tile mode
         tile-major (all fields of tile 0, then tile 1, ...: the order vfml.runner uses), so that
         consecutive items share their crop's cached frames."""
+        if tiles == [None] and hasattr(proc, "compute_optical_flow_resident_batch"):
+            step = proc.TRI_BATCH       # (whole frames: the processor passes several fields per call where it can)
+            for k0 in range(0, len(idxs), step):
+                for j, f in enumerate(proc.compute_optical_flow_resident_batch(clip, idxs[k0:k0 + step])):
+                    dst[k0 + j].copy_(f)
+            return
         for t in tiles:
             for k, i in enumerate(idxs):
                 f = proc.compute_optical_flow_resident(clip, i, tile=t)

@@ -260,3 +260,30 @@ def test_full_size_properties_1080p_and_4k_tiles(gpu):
         assert np.array_equal(pasted[t['y']:t['y'] + t['height'], t['x']:t['x'] + t['width']], ref)
     net.clear_feature_cache()
     torch.cuda.empty_cache()
+
+
+def test_bof_fields_batched_equal_fields_one_by_one(gpu):
+    """`--vf-architecture bof`, seq 9: consecutive interior fields go through the tri-frame network four at a
+    time (tri_batch); clip-edge fields, whose centre triples repeat frames, one by one.  Both orders of
+    evaluation give the same bits, and the runner's job equals the per-frame API."""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.runner import run_sharded
+    from vfml.synth import synthetic_clip
+    net, _ = _pair(network="BOFNet")
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=9, architecture="bof", dataset="things")
+    proc.core.model = net
+    frames = synthetic_clip(12, 128, 160)
+    clip = proc.upload_clip(frames)
+    batched = [f.clone() for f in proc.compute_optical_flow_resident_batch(clip, list(range(12)))]
+    net.clear_feature_cache()
+    for i in range(12):
+        one = proc.compute_optical_flow_resident(clip, i)
+        assert torch.equal(batched[i], one), i
+    net.clear_feature_cache()
+    job = run_sharded(proc, clip, range(12))
+    assert np.array_equal(job[5], batched[5].cpu().numpy()) and np.array_equal(job[0], batched[0].cpu().numpy())
+    assert np.array_equal(job[7], proc.compute_optical_flow(frames, 7))

@@ -7,6 +7,7 @@ fixed 1280x1280 row-major tiles with ragged edge tiles and hard seams (:73-110, 
 """
 import collections
 import hashlib
+import os
 
 import numpy as np
 import torch
@@ -210,6 +211,40 @@ class VideoFlowProcessor:
             return flows[0, flows.shape[1] // 2].permute(1, 2, 0)
         batch = (win.float() / 255.0).permute(0, 3, 1, 2).unsqueeze(0)
         return self.core.compute_flow_from_tensor(batch).permute(1, 2, 0)
+
+    def compute_optical_flow_resident_batch(self, clip, frame_idxs):
+        """Fields of several frames of a clip already in HBM -> list of device tensors [H,W,2].
+        For the tri-frame network (`--vf-architecture bof`) runs of consecutive frames whose centre triples are
+        (j-1, j, j+1) go through the engine in one pass (forward_u8(..., tri_batch=True)): at 720p a single
+        triple keeps a third of the chip busy.  Everything else falls back to one call per frame.  Same
+        fields as compute_optical_flow_resident, bit for bit."""
+        self._require_model()
+        from vfml.network import take_frames
+        model = self.core.model
+        frame_idxs = list(frame_idxs)
+        F, H, W = clip.shape[0], clip.shape[1], clip.shape[2]
+        can_batch = getattr(model, "tri_frame", False) and hasattr(model, "forward_u8") and H % 8 == 0 and W % 8 == 0
+        lo = self.sequence_length // 2 - 1
+        triples = [self.window_indices(F, i)[lo:lo + 3] if self.sequence_length >= 3 else None for i in frame_idxs]
+        out, k = [], 0
+        while k < len(frame_idxs):
+            e = k
+            if can_batch and triples[k] is not None and triples[k][0] + 1 == triples[k][1] == triples[k][2] - 1:
+                while (e + 1 < len(frame_idxs) and e + 1 - k < self.TRI_BATCH and
+                       triples[e + 1] == [t + 1 for t in triples[e]]):
+                    e += 1
+            if e == k:
+                out.append(self.compute_optical_flow_resident(clip, frame_idxs[k]))
+            else:
+                B = e - k + 1
+                ids = list(range(triples[k][0], triples[e][2] + 1))              # B + 2 consecutive frames
+                keys = [(clip.data_ptr(), clip._version, i, None) for i in ids]
+                flows, _ = model.forward_u8(take_frames(clip, ids), return_lowres=False, frame_keys=keys, tri_batch=True)
+                out.extend(flows[0, B + j].permute(1, 2, 0) for j in range(B))
+            k = e + 1
+        return out
+
+    TRI_BATCH = int(os.environ.get("VFML_TRI_BATCH", "8"))        # fields per pass of the tri-frame network
 
     # -- misc -------------------------------------------------------------------------------
     def is_model_loaded(self):

@@ -238,7 +238,7 @@ class MOFNetHIP(_Holder):
         return self._run(src.contiguous(), src.shape[0], src.shape[2], src.shape[3], return_lowres)
 
     @torch.no_grad()
-    def forward_u8(self, frames, return_lowres=True, frame_keys=None):
+    def forward_u8(self, frames, return_lowres=True, frame_keys=None, tri_batch=False):
         """frames: uint8 [N, H, W, 3] RGB on the GPU; /255 happens in the K1 kernel (same fp32 ops
         as the reference's host-side conversion), saving the 4x larger float upload.
 
@@ -246,14 +246,21 @@ class MOFNetHIP(_Holder):
         independently (instance norm is per image), so their outputs depend on the frame alone:
         with keys the engine keeps the per-frame feature maps, pooled target pyramids and context
         maps of recently seen frames and encodes only the frames it has not seen - in a sliding
-        window that is 1 of N.  The caller promises that equal keys mean equal pixels."""
+        window that is 1 of N.  The caller promises that equal keys mean equal pixels.
+
+        tri_batch (tri-frame networks, `--vf-architecture bof`): the N frames are B = N-2 overlapping triples
+        (j-1, j, j+1) - B consecutive fields of a job in one pass, every centre frame its own problem; the
+        output holds their 2B flows (forward flows first), field j's pick is flow B + j.  Same values as B
+        separate calls; at 720p one triple fills a third of the chip."""
         if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8
                 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 [N,H,W,3] device tensor")
         if frame_keys is not None and len(frame_keys) != frames.shape[0]:
             raise ValueError("frame_keys must have one entry per frame")
+        if tri_batch and not self.tri_frame:
+            raise ValueError("tri_batch applies to tri-frame (BOF) networks")
         return self._run(frames.contiguous(), frames.shape[0], frames.shape[1], frames.shape[2], return_lowres,
-                         frame_keys)
+                         frame_keys, tri_batch)
 
     # ------------------------------------------------------------------ per-frame encoder cache
     FEATURE_CACHE_FRAMES = 12
@@ -368,11 +375,11 @@ class MOFNetHIP(_Holder):
                     self._cache_put("c", keys[j], out[j])
         return out
 
-    def _run(self, src, N, H, W, return_lowres, frame_keys=None):
+    def _run(self, src, N, H, W, return_lowres, frame_keys=None, tri_batch=False):
         cfg = self.cfg
         if N < 3:
             raise ValueError(f"need at least 3 frames, got {N}")
-        if self.tri_frame and N > 3:
+        if self.tri_frame and N > 3 and not tri_batch:
             lo = N // 2 - 1
             src = src[lo:lo + 3].contiguous()
             frame_keys = frame_keys[lo:lo + 3] if frame_keys is not None else None
@@ -436,7 +443,7 @@ class MOFNetHIP(_Holder):
                         # (a backward problem's level 0 computed directly uses VFML_CONV_SWAP_CROSS, the addition
                         # order of a transposed forward volume: both routes give the same bits)
                         rk = ("p", keys[tgt], keys[c]) if pk is not None else None
-                        gemm_form = AF == hip.FMT_S16 and Pn % 4 == 0 and Sl[0] >= 1024 and not self.tri_frame
+                        gemm_form = AF == hip.FMT_S16 and Pn % 4 == 0 and Sl[0] >= 1024
                         dual = (rk is not None and d == "f" and gemm_form and ("p", rk) not in self._feat_cache
                                 and not os.environ.get("VFML_NO_DUAL"))      # (A/B switch; results are identical)
                         rev = None
@@ -503,8 +510,12 @@ class MOFNetHIP(_Holder):
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # temporal stack fusion: 3x1 conv along the frame axis of the motion features
                 wgt, b = P[f"{ub}.tprop"]
-                hip.conv2d(G, 128, GLD, 1, M, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                if self.tri_frame:     # every centre frame is its own problem: its neighbours are the zero padding
+                    hip.conv2d(G, 128, GLD, M, 1, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                else:
+                    hip.conv2d(G, 128, GLD, 1, M, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # SepConvGRU, horizontal then vertical
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]

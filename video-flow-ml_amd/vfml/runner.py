@@ -38,8 +38,7 @@ def _run_streaming(proc, clip, frame_indices, on_field):
             out[k] = ring[r].numpy()
             on_field(k, out[k])
 
-    for k, f in enumerate(frame_indices):
-        flow = proc.compute_optical_flow_resident(clip, f)
+    for k, flow in _fields_in_order(proc, clip, frame_indices):
         if not on_gpu:
             out[k] = flow.numpy()
             on_field(k, out[k])
@@ -53,6 +52,18 @@ def _run_streaming(proc, clip, frame_indices, on_field):
         drain(1)                                       # hand over field k-1 while field k is in flight
     drain(0)
     return out
+
+
+def _fields_in_order(proc, clip, frame_indices):
+    """(position, field) for every frame, whole frames: a few fields per pass where the processor can batch
+    them (the tri-frame network, compute_optical_flow_resident_batch), else one call per field."""
+    batch = getattr(proc, "compute_optical_flow_resident_batch", None)
+    step = getattr(proc, "TRI_BATCH", 1) if batch is not None else 1
+    for k0 in range(0, len(frame_indices), step):
+        chunk = frame_indices[k0:k0 + step]
+        flows = batch(clip, chunk) if batch is not None else [proc.compute_optical_flow_resident(clip, f) for f in chunk]
+        for j, flow in enumerate(flows):
+            yield k0 + j, flow
 
 
 def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None, on_field=None):
@@ -71,11 +82,17 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     lo, hi = bounds[rank]
     local = torch.empty(sizes[rank], dtype=torch.float32, device=clip.device)
     off = 0
-    for f, t in items[lo:hi]:
-        flow = proc.compute_optical_flow_resident(clip, f, tile=tiles[t])
-        n = flow.numel()
-        local[off:off + n].copy_(flow.reshape(-1))
-        off += n
+    if len(tiles) == 1:                                # whole frames: batched where the processor can
+        for _, flow in _fields_in_order(proc, clip, [f for f, _ in items[lo:hi]]):
+            n = flow.numel()
+            local[off:off + n].copy_(flow.reshape(-1))
+            off += n
+    else:
+        for f, t in items[lo:hi]:
+            flow = proc.compute_optical_flow_resident(clip, f, tile=tiles[t])
+            n = flow.numel()
+            local[off:off + n].copy_(flow.reshape(-1))
+            off += n
     parts = vdist.gather_to_rank0(local, sizes, group=group)
     if rank != 0:
         return None
