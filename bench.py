@@ -114,7 +114,7 @@ def main():
         tile-major (all fields of tile 0, then tile 1, ...: the order vfml.runner uses), so that
         consecutive items share their crop's cached frames."""
         if tiles == [None] and hasattr(proc, "compute_optical_flow_resident_batch"):
-            step = proc.TRI_BATCH       # (whole frames: the processor passes several fields per call where it can)
+            step = getattr(proc, "TRI_BATCH", None) or getattr(proc, "PAIR_BATCH", 1)   # (several fields per call where it can)
             for k0 in range(0, len(idxs), step):
                 for j, f in enumerate(proc.compute_optical_flow_resident_batch(clip, idxs[k0:k0 + step])):
                     dst[k0 + j].copy_(f)

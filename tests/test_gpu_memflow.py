@@ -153,3 +153,32 @@ def test_memflow_resident_loop_reuses_encoder_outputs_exactly(gpu, tmp_path, mon
         a = proc.compute_optical_flow_resident(clip, i).cpu().numpy()
         assert np.array_equal(a, eng.compute_optical_flow(frames, i)), i
     assert sum(1 for k in net._feat_cache if k[0] == "f") >= 2          # the cache is in use
+
+
+def test_memflow_fields_batched_equal_fields_one_by_one(gpu, tmp_path, monkeypatch):
+    """Job loops pass three consecutive pairs per call of the engine (forward_pairs): every pair keeps its own
+    attention operator and fresh memory, the fields are the same bits as one call per pair - padded size,
+    frame 0 (the pair (0, 0)) on the single path."""
+    import contextlib
+    import io
+    import os
+    import numpy as np
+    from processing.memflow_inference import MemFlowInference
+    from vfml.memflow_net import memflow_cfg, seeded_memflow_state_dict
+    from vfml.runner import run_sharded
+    from vfml.synth import synthetic_clip
+    os.makedirs(tmp_path / "MemFlow_ckpt")
+    torch.save(seeded_memflow_state_dict(memflow_cfg(), 0), tmp_path / "MemFlow_ckpt" / "MemFlowNet_sintel.pth")
+    monkeypatch.chdir(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        eng = MemFlowInference("cuda", sequence_length=3)
+        eng.load_model()
+    proc = eng.get_processor()
+    frames = synthetic_clip(8, 132, 200)
+    clip = proc.upload_clip(frames)
+    batched = [f.clone() for f in proc.compute_optical_flow_resident_batch(clip, list(range(8)))]
+    proc.core_engine.model.clear_feature_cache()
+    for i in range(8):
+        assert torch.equal(batched[i], proc.compute_optical_flow_resident(clip, i)), i
+    job = run_sharded(proc, clip, range(8))
+    assert np.array_equal(job[6], batched[6].cpu().numpy()) and np.array_equal(job[0], batched[0].cpu().numpy())

@@ -93,6 +93,31 @@ class MemFlowCore:
             out, mode = frames, 2
         return (out, mode) if return_mode else out
 
+    @staticmethod
+    def normalise_as(frames, mode):
+        """The branch `mode` of normalise() (0: 0..255 values, 1: 0..2, 2: already normalised), no host sync."""
+        if mode == 0:
+            return 2 * (frames / 255.0) - 1.0
+        if mode == 1:
+            return 2 * frames - 1.0
+        return frames
+
+    def compute_pair_flows(self, frames_tensor, mode, frame_keys=None):
+        """[1,B+1,3,H,W] raw frame values on the device, B consecutive pairs (k, k+1), normalised by branch `mode`
+        of the range heuristic (the caller knows each field's window maximum) -> flows [B,2,H,W] on the device.
+        An extension for job loops: B fields per pass of the engine, same values as B single calls."""
+        if self.model is None:
+            raise RuntimeError("Model not loaded. Call load_model() first.")
+        with torch.no_grad():
+            x = self.normalise_as(frames_tensor.to(self.device).float(), mode)
+            padder = InputPadder(x.shape)
+            x = padder.pad(x)
+            keys = None
+            if frame_keys is not None:
+                keys = [(k, mode, tuple(x.shape[-2:])) for k in frame_keys]
+            _, flows = self.model.forward_pairs(x, None, frame_keys=keys)
+            return padder.unpad(flows)
+
     def compute_flow_from_tensor(self, frames_tensor: torch.Tensor, keep_on_device: bool = False,
                                  frame_keys=None) -> torch.Tensor:
         """[1,T,3,H,W] (0..255, 0..1 or -1..1 floats, any device) -> flow [2,H,W] on the CPU

@@ -3,6 +3,7 @@
 API mirror of reference processing/memflow_processor.py:20-256: the window is the `sequence_length`
 frames ENDING at frame_idx, front-padded by repeating the first (:113-122); frames stay 0..255 floats on
 the CPU (:124-139); MemFlow never tiles — the tile methods return one full-frame "tile" (:190-247)."""
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -81,6 +82,51 @@ class MemFlowProcessor:
         x = take_frames(clip, ids).permute(0, 3, 1, 2).float().unsqueeze(0)
         keys = [(clip.data_ptr(), clip._version, i) for i in ids]      # same clip, same frame = same pixels
         return self.core_engine.compute_flow_from_tensor(x, keep_on_device=True, frame_keys=keys).permute(1, 2, 0)
+
+    PAIR_BATCH = int(os.environ.get("VFML_PAIR_BATCH", "3"))   # fields per pass of the engine in job loops
+
+    def _frame_maxima(self, clip):
+        """Largest value of every frame of a resident clip (one pass + one sync per clip): the range heuristic
+        of the reference's script looks at the window's maximum."""
+        key = (clip.data_ptr(), clip._version, tuple(clip.shape))
+        if getattr(self, "_maxima_key", None) != key:
+            self._maxima = clip.reshape(clip.shape[0], -1).amax(dim=1).tolist()
+            self._maxima_key = key
+        return self._maxima
+
+    def compute_optical_flow_resident_batch(self, clip, frame_idxs):
+        """Fields of several frames of a resident clip -> list of device tensors [H,W,2].  Runs of consecutive
+        frames (pairs (i-1, i), same branch of the range heuristic) go through the engine PAIR_BATCH at a time;
+        frame 0 (pair (0, 0)) and anything irregular one by one.  Same fields as compute_optical_flow_resident."""
+        from vfml.network import take_frames
+        frame_idxs = list(frame_idxs)
+        model = self.core_engine.model
+        if not hasattr(model, "forward_pairs") or not clip.is_cuda:
+            return [self.compute_optical_flow_resident(clip, i) for i in frame_idxs]
+        mx = self._frame_maxima(clip)
+
+        def mode_of(i):
+            m = max(mx[j] for j in self.window_indices(i))
+            return 0 if m > 2.0 else (1 if m > 1.0 else 2)
+
+        out, k = [], 0
+        while k < len(frame_idxs):
+            i = frame_idxs[k]
+            e = k
+            if i >= 1:
+                while (e + 1 < len(frame_idxs) and e + 1 - k < self.PAIR_BATCH and frame_idxs[e + 1] == frame_idxs[e] + 1
+                       and mode_of(frame_idxs[e + 1]) == mode_of(i)):
+                    e += 1
+            if e == k:
+                out.append(self.compute_optical_flow_resident(clip, i))
+            else:
+                ids = list(range(i - 1, frame_idxs[e] + 1))                      # B + 1 consecutive frames
+                x = take_frames(clip, ids).permute(0, 3, 1, 2).float().unsqueeze(0)
+                keys = [(clip.data_ptr(), clip._version, j) for j in ids]
+                flows = self.core_engine.compute_pair_flows(x, mode_of(i), frame_keys=keys)
+                out.extend(flows[j].permute(1, 2, 0) for j in range(flows.shape[0]))
+            k = e + 1
+        return out
 
     def compute_optical_flow_with_progress(self, frames, frame_idx, tile_pbar=None) -> np.ndarray:
         if tile_pbar is not None:

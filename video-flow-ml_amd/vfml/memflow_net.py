@@ -136,13 +136,24 @@ class MemFlowNetHIP(MOFNetHIP):
         frame_keys: optional pair of hashable ids of the two frames (same id = same normalised pixels): the
         feature encoder output of a frame is then kept, so a frame that is "current" in one call and
         "previous" in the next is encoded once (results bit-identical)."""
-        if not isinstance(pair, torch.Tensor) or not pair.is_cuda:
-            raise RuntimeError("MemFlowNetHIP runs on an MI355X (HIP) device only; got "
-                               f"{getattr(pair, 'device', type(pair))}. There is no CPU fallback in the shipped engine.")
-        if pair.dim() != 5 or pair.shape[0] != 1 or pair.shape[1] != 2 or pair.shape[2] != 3:
+        if isinstance(pair, torch.Tensor) and pair.dim() == 5 and pair.shape[1] != 2:
             raise ValueError(f"pair must be [1,2,3,H,W], got {tuple(pair.shape)}")
+        return self.forward_pairs(pair, data, frame_keys)
+
+    @torch.no_grad()
+    def forward_pairs(self, frames, data=None, frame_keys=None):
+        """frames: float [1, B+1, 3, H, W] in [-1, 1] on the GPU: B overlapping pairs (k, k+1) - B consecutive
+        fields of a job in one pass (every pair its own fresh-memory step, exactly as B separate calls; at
+        1080p one pair leaves most tiles of the update-block convolutions' last round empty).
+        Returns (flow_low [B,2,h,w], flow [B,2,H,W])."""
+        if not isinstance(frames, torch.Tensor) or not frames.is_cuda:
+            raise RuntimeError("MemFlowNetHIP runs on an MI355X (HIP) device only; got "
+                               f"{getattr(frames, 'device', type(frames))}. There is no CPU fallback in the shipped engine.")
+        if frames.dim() != 5 or frames.shape[0] != 1 or frames.shape[1] < 2 or frames.shape[2] != 3:
+            raise ValueError(f"frames must be [1,B+1,3,H,W], got {tuple(frames.shape)}")
         cfg = self.cfg
-        src = pair[0].float().contiguous()
+        src = frames[0].float().contiguous()
+        B = src.shape[0] - 1
         H, W = src.shape[2], src.shape[3]
         if H % 8 or W % 8:
             raise ValueError("H and W must be multiples of 8 (use InputPadder)")
@@ -152,6 +163,7 @@ class MemFlowNetHIP(MOFNetHIP):
             raise ValueError(f"frame {H}x{W} too small for a {L}-level correlation pyramid")
         dev = src.device
         Pn = h * w
+        MP = B * Pn
         P = self._pack(dev)
         if self._precision() != "f16x3":
             raise ValueError("the MemFlow path is built on the split-f16 kernels: cfg.precision must be 'f16x3'")
@@ -170,124 +182,132 @@ class MemFlowNetHIP(MOFNetHIP):
             ldl = [(s + 31) // 32 * 32 for s in Sl]
             keys = None
             if frame_keys is not None:
-                if len(frame_keys) != 2:
-                    raise ValueError("frame_keys must hold one id per frame of the pair")
+                if len(frame_keys) != B + 1:
+                    raise ValueError("frame_keys must hold one id per frame")
                 keys = [("memflow", k, H, W, L, self._precision(), self._packed_serial) for k in frame_keys]
-            feats = self._frame_features(src, [0, 1], keys, H, W, P, dev, L, hl, wl, Sl)
-            ctx = self._frame_context_plain(src, H, W, P, dev, Pn, AF)
-            pyr = [self._buf(f"mpyr_{l}", Pn * ldl[l], dev) for l in range(L)]
-            for l in range(L):
-                hip.conv2d(feats[0][0], D, D, 1, 1, Pn, feats[1][1][l], None, Sl[l], 1, 1, pyr[l], ldl[l],
-                           out_scale=1.0 / float(D) ** 0.5 / self.FMAP_ROW_SCALE, in_fmt=AF)   # query rows carry x16
+            feats = self._frame_features(src, list(range(B + 1)), keys, H, W, P, dev, L, hl, wl, Sl)
+            ctx = self._frame_context_plain(src, B, H, W, P, dev, Pn, AF)       # cnet on the B previous frames
+            pyrs = []
+            for k in range(B):       # pair k: queries = frame k, targets = frame k+1
+                pyr = [self._buf(f"mpyr{k}_{l}", Pn * ldl[l], dev) for l in range(L)]
+                for l in range(L):
+                    hip.conv2d(feats[k][0], D, D, 1, 1, Pn, feats[k + 1][1][l], None, Sl[l], 1, 1, pyr[l], ldl[l],
+                               out_scale=1.0 / float(D) ** 0.5 / self.FMAP_ROW_SCALE, in_fmt=AF)   # query rows carry x16
+                pyrs.append(pyr)
 
             GLD, Z, RH, HH, INP, MF, MT = 768, 0, 128, 256, 384, 512, 640
-            G = self._buf("gru_state", Pn * GLD, dev)
-            G.view(Pn, GLD)[:, HH:HH + 256].copy_(ctx.view(Pn, 256))
+            G = self._buf("gru_state", MP * GLD, dev)
+            G.view(MP, GLD)[:, HH:HH + 256].copy_(ctx.view(MP, 256))
             # context parts of the GRU gates (+ bias), once per field
             gate_add = {}
             for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                 for g, co in (("zr", 256), ("q", 128)):
                     wgt, b = P[f"{ub}.gru.conv{g}{k}.ctx"]
-                    a = self._buf(f"gate_add_{g}{k}", Pn * co, dev)
-                    hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, co, kh, kw, a, co, in0_off=INP, pad_h=kh // 2,
+                    a = self._buf(f"gate_add_{g}{k}", MP * co, dev)
+                    hip.conv2d(G, 128, GLD, B, h, w, wgt, b, co, kh, kw, a, co, in0_off=INP, pad_h=kh // 2,
                                pad_w=kw // 2, in_fmt=AF)
                     gate_add[g + k] = a
 
-            # memory read-out operator: attn = softmax(q k^T / sqrt(d)), P x P, once per field
+            # memory read-out operator: attn = softmax(q k^T / sqrt(d)), P x P per pair, once per field
             P8 = (Pn + 7) // 8 * 8
             ldA = (P8 + 31) // 32 * 32
-            qmap = self._buf("att_q", Pn * AD, dev)
-            kmap = self._buf("att_k", Pn * AD, dev)
+            qmap = self._buf("att_q", MP * AD, dev)
+            kmap = self._buf("att_k", MP * AD, dev)
             wgt, b = P["query"]
-            hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, qmap, AD, in0_off=INP, in_fmt=AF, out_fmt=AF)
+            hip.conv2d(G, 128, GLD, B, h, w, wgt, b, AD, 1, 1, qmap, AD, in0_off=INP, in_fmt=AF, out_fmt=AF)
             wgt, b = P["key"]
-            hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, kmap, AD, in0_off=INP, in_fmt=AF)
-            kw_ = hip.SplitWeight(Pn, AD, dev).fill(kmap, scale=16.0)
+            hip.conv2d(G, 128, GLD, B, h, w, wgt, b, AD, 1, 1, kmap, AD, in0_off=INP, in_fmt=AF)
             scores = self._buf("att_scores", Pn * ldA, dev)
-            hip.conv2d(qmap, AD, AD, 1, 1, Pn, kw_, None, Pn, 1, 1, scores, ldA, out_scale=1.0 / float(AD) ** 0.5,
-                       in_fmt=AF)
-            attn = self._buf("att_probs", Pn * ldA, dev)
-            hip.softmax_rows_s16(scores, Pn, Pn, ldA, attn, ldA)
+            attn = []
+            for k in range(B):
+                kw_ = hip.SplitWeight(Pn, AD, dev).fill(kmap, src_off=k * Pn * AD, scale=16.0)
+                hip.conv2d(qmap, AD, AD, 1, 1, Pn, kw_, None, Pn, 1, 1, scores, ldA, in0_off=k * Pn * AD,
+                           out_scale=1.0 / float(AD) ** 0.5, in_fmt=AF)
+                a = self._buf(f"att_probs{k}", Pn * ldA, dev)
+                hip.softmax_rows_s16(scores, Pn, Pn, ldA, a, ldA)
+                attn.append(a)
 
-            corr = self._buf("mcorr", Pn * cor_p, dev, zero=True)
-            c1 = self._buf("c1", Pn * 256, dev)
-            cf = self._buf("cf", Pn * 256, dev)
-            f1 = self._buf("f1", Pn * 128, dev)
-            fh = self._buf("fh", Pn * 256, dev)
-            val = self._buf("att_v", Pn * AD, dev)
-            flow4 = self._buf("flow4", Pn * 4, dev)
-            delta = self._buf("mdelta", Pn * 4, dev, zero=True)     # channels 2,3 stay zero: no backward flow here
-            coords1 = self._buf("coords1", Pn * 4, dev)
+            corr = self._buf("mcorr", MP * cor_p, dev, zero=True)
+            c1 = self._buf("c1", MP * 256, dev)
+            cf = self._buf("cf", MP * 256, dev)
+            f1 = self._buf("f1", MP * 128, dev)
+            fh = self._buf("fh", MP * 256, dev)
+            val = self._buf("att_v", MP * AD, dev)
+            flow4 = self._buf("flow4", MP * 4, dev)
+            delta = self._buf("mdelta", MP * 4, dev, zero=True)     # channels 2,3 stay zero: no backward flow here
+            coords1 = self._buf("coords1", MP * 4, dev)
             vt = hip.SplitWeight(AD, P8, dev)
-            rows_per_call = max(128, ((1 << 30) // (ldA * 4) - 2) // 128 * 128)   # each A window < 1 GiB
 
-            hip.coords_init(coords1, 1, h, w)
-            hip.coords_update(coords1, None, 1, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
+            hip.coords_init(coords1, B, h, w)
+            hip.coords_update(coords1, None, B, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
                               fmt_b=AF)
             for it in range(cfg.decoder_depth):
-                hip.corr_lookup(pyr, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, cor_p, out_fmt=AF)
+                hip.corr_lookup(pyrs, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, cor_p, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convc1"]
-                hip.conv2d(corr, cor_p, cor_p, 1, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
+                hip.conv2d(corr, cor_p, cor_p, B, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
                            in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convc2"]
-                hip.conv2d(c1, 256, 256, 1, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+                hip.conv2d(c1, 256, 256, B, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
                            in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convf1"]
-                hip.conv2d(flow4, 4, 4, 1, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                hip.conv2d(flow4, 4, 4, B, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
                            out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convf2"]
-                hip.conv2d(f1, 128, 128, 1, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
+                hip.conv2d(f1, 128, 128, B, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # motion features [conv out (124) | fx, fy, 0, 0]: the flow quad is written by coords_update
                 wgt, b = P[f"{ub}.encoder.conv"]
-                hip.conv2d(cf, 256, 256, 1, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
+                hip.conv2d(cf, 256, 256, B, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
-                # value map and memory read-out  m_global = m + gamma * attn . v
+                # value map and memory read-out  m_global = m + gamma * attn . v  (per pair: its own attention)
                 wgt, b = P[f"{ub}.value"]
-                hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, AD, 1, 1, val, AD, in0_off=MF, in_fmt=AF)
-                vt.fill_transposed(val, Pn, ld=AD, scale=16.0)
-                # rows as the batch axis (1x1 "images"): one GEMM over the whole 4.2 GB attention matrix - the
-                # LDS-DMA kernel bases its source descriptor at each tile's first row
-                hip.conv2d(attn, P8, ldA, Pn, 1, 1, vt, None, AD, 1, 1, G, GLD, out_off=MT, out_scale=gamma,
-                           epilogue=hip.EPI_ADD_AUX, aux0=G, ld_aux0=GLD, aux0_off=MF, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                hip.conv2d(G, 128, GLD, B, h, w, wgt, b, AD, 1, 1, val, AD, in0_off=MF, in_fmt=AF)
+                for k in range(B):
+                    vt.fill_transposed(val, Pn, ld=AD, scale=16.0, src_off=k * Pn * AD)
+                    # rows as the batch axis (1x1 "images"): one GEMM over the whole 4.2 GB attention matrix -
+                    # the LDS-DMA kernel bases its source descriptor at each tile's first row
+                    hip.conv2d(attn[k], P8, ldA, Pn, 1, 1, vt, None, AD, 1, 1, G, GLD, out_off=k * Pn * GLD + MT,
+                               out_scale=gamma, epilogue=hip.EPI_ADD_AUX, aux0=G, ld_aux0=GLD, aux0_off=k * Pn * GLD + MF,
+                               in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
-                    hip.conv2d(G, 128, GLD, 1, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
+                    hip.conv2d(G, 128, GLD, B, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
                                in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
                                addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                     wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
-                    hip.conv2d(G, 128, GLD, 1, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
+                    hip.conv2d(G, 128, GLD, B, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
                                in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
                                aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
                                in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                 wgt, b = P[f"{ub}.flow_head.conv1"]
-                hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                hip.conv2d(G, 128, GLD, B, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.flow_head.conv2"]
-                hip.conv2d(fh, 256, 256, 1, h, w, wgt, b, 2, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
-                hip.coords_update(coords1, delta, 1, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                hip.conv2d(fh, 256, 256, B, h, w, wgt, b, 2, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
+                hip.coords_update(coords1, delta, B, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
                                   flow_b_off=MF + 124, fmt_b=AF)
 
-            mask = self._buf("mmask", Pn * 576, dev)
+            mask = self._buf("mmask", MP * 576, dev)
             wgt, b = P[f"{ub}.mask.0"]
-            hip.conv2d(G, 128, GLD, 1, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+            hip.conv2d(G, 128, GLD, B, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                        epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
             wgt, b = P[f"{ub}.mask.2"]
-            hip.conv2d(fh, 256, 256, 1, h, w, wgt, b, 576, 1, 1, mask, 576, out_scale=0.25, in_fmt=AF)
-            up = torch.empty(H, W, 2, device=dev, dtype=torch.float32)
-            hip.convex_upsample(coords1, 0, 0, mask, 0, 576, h, w, up.view(-1))
-            low = flow4.view(h, w, 4)[..., :2].permute(2, 0, 1).unsqueeze(0).clone()
-        return low, up.permute(2, 0, 1).unsqueeze(0)
+            hip.conv2d(fh, 256, 256, B, h, w, wgt, b, 576, 1, 1, mask, 576, out_scale=0.25, in_fmt=AF)
+            up = torch.empty(B, H, W, 2, device=dev, dtype=torch.float32)
+            for k in range(B):
+                hip.convex_upsample(coords1, k * Pn * 4, 0, mask, k * Pn * 576, 576, h, w, up.view(-1), out_off=k * H * W * 2)
+            low = flow4.view(B, h, w, 4)[..., :2].permute(0, 3, 1, 2).clone()
+        return low, up.permute(0, 3, 1, 2)
 
-    def _frame_context_plain(self, src, H, W, P, dev, Pn, AF):
-        """cnet on the previous frame (index 0 of the pair): [Pn*256] = tanh | relu halves."""
-        frames = self._buf("frames", H * W * 4, dev)
-        hip.frames_to_nhwc4(src[0:1].contiguous(), 1, H, W, float(self.cfg.input_scale), float(self.cfg.input_shift),
+    def _frame_context_plain(self, src, B, H, W, P, dev, Pn, AF):
+        """cnet on the previous frame of every pair (frames 0..B-1): [B*Pn*256] = tanh | relu halves."""
+        frames = self._buf("frames", B * H * W * 4, dev)
+        hip.frames_to_nhwc4(src[0:B].contiguous(), B, H, W, float(self.cfg.input_scale), float(self.cfg.input_shift),
                             frames)
-        ctx = torch.empty(Pn * 256, device=dev)
-        self._encoder("cnet", frames, 1, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim, out_fmt=AF)
+        ctx = torch.empty(B * Pn * 256, device=dev)
+        self._encoder("cnet", frames, B, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim, out_fmt=AF)
         return ctx
 
 

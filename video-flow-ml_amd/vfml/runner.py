@@ -58,7 +58,7 @@ def _fields_in_order(proc, clip, frame_indices):
     """(position, field) for every frame, whole frames: a few fields per pass where the processor can batch
     them (the tri-frame network, compute_optical_flow_resident_batch), else one call per field."""
     batch = getattr(proc, "compute_optical_flow_resident_batch", None)
-    step = getattr(proc, "TRI_BATCH", 1) if batch is not None else 1
+    step = (getattr(proc, "TRI_BATCH", None) or getattr(proc, "PAIR_BATCH", 1)) if batch is not None else 1
     for k0 in range(0, len(frame_indices), step):
         chunk = frame_indices[k0:k0 + step]
         flows = batch(clip, chunk) if batch is not None else [proc.compute_optical_flow_resident(clip, f) for f in chunk]
