@@ -51,6 +51,10 @@ def main():
                     help="mof1080p = BASELINE.json configs[1] (the headline, default); the others are the remaining "
                          "GPU configs, measured with the same protocol for DESIGN.md (not the driver's line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-output", action="store_true",
+                    help="compute all 2(T-2) flows of the model output per field instead of the one the reference "
+                         "path keeps ([0, shape[1]//2]); the default drops, in the last two iterations, the centre "
+                         "frames that cannot influence that flow (bit-identical for it)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads for the CPU baseline (0 = this process's CPU share: affinity / cgroup quota, "
                          "capped at 16 - the per-GPU share of the pool's boxes)")
@@ -67,6 +71,8 @@ def main():
         args.seq = 3
     if args.workload != "mof1080p":
         args.no_cpu_baseline = True
+    if args.full_output:
+        os.environ["VFML_FULL_OUTPUT"] = "1"      # read by processing/videoflow_processor.py at import
     from vfml import dist as vdist, get_cfg, hip
     from vfml.synth import synthetic_clip
     from vfml.weights import write_seeded_checkpoint
@@ -187,7 +193,11 @@ def main():
                                + f" seq_len={T} {args.width}x{args.height} synthetic clip, decoder_depth={depth}, "
                                  f"seeded weights",
                    "fields_per_gpu": K, "clip_frames_per_gpu": nframes, "parallelism": f"frames-dp{world}",
-                   "inputs": "uint8 clip resident in HBM", "outputs": "[H,W,2] f32 in HBM, gathered to rank 0"},
+                   "inputs": "uint8 clip resident in HBM", "outputs": "[H,W,2] f32 in HBM, gathered to rank 0",
+                   "model_output": ("all 2(T-2) flows per field (--full-output)" if args.full_output else
+                                    "the flow the reference path keeps, [0, shape[1]//2]; the last two iterations "
+                                    "skip the centre frames outside its dependency cone (bit-identical for it; "
+                                    "--full-output computes all 2(T-2))")},
         "compute_ms_per_step": 1000.0 * t_compute / K,
         "gather_ms": 1000.0 * t_gather,
     }

@@ -126,7 +126,7 @@ class VideoFlowProcessor:
                 while len(self._dev_frames) > HOST_FRAME_CACHE:
                     self._dev_frames.popitem(last=False)
         win = torch.stack([self._dev_frames[keys[i]] for i in ids])
-        flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=[keys[i] for i in ids])
+        flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=[keys[i] for i in ids], pick_only=self.PICK_ONLY)
         return flows[0, flows.shape[1] // 2].permute(1, 2, 0).cpu().numpy()
 
     def compute_optical_flow(self, frames, frame_idx):
@@ -207,7 +207,7 @@ class VideoFlowProcessor:
             # a frame of this clip (and tile) is the same pixels in every window that contains it:
             # let the engine reuse its per-frame encoder outputs across the sliding windows
             keys = [(clip.data_ptr(), clip._version, i, rect) for i in frame_ids]
-            flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=keys)
+            flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=keys, pick_only=self.PICK_ONLY)
             return flows[0, flows.shape[1] // 2].permute(1, 2, 0)
         batch = (win.float() / 255.0).permute(0, 3, 1, 2).unsqueeze(0)
         return self.core.compute_flow_from_tensor(batch).permute(1, 2, 0)
@@ -245,6 +245,11 @@ class VideoFlowProcessor:
         return out
 
     TRI_BATCH = int(os.environ.get("VFML_TRI_BATCH", "8"))        # fields per pass of the tri-frame network
+    # The reference keeps ONE of the model's 2(T-2) flows per call (`flow_predictions[0, shape[1]//2]`,
+    # processing/videoflow_core.py:194-195).  By default the engine is asked for that flow only and drops, in
+    # the last iterations, the centre frames outside its dependency cone (bit-identical for that flow);
+    # VFML_FULL_OUTPUT=1 (bench.py --full-output) computes all of them as `model(x, {})` does.
+    PICK_ONLY = not os.environ.get("VFML_FULL_OUTPUT")
 
     # -- misc -------------------------------------------------------------------------------
     def is_model_loaded(self):

@@ -238,7 +238,7 @@ class MOFNetHIP(_Holder):
         return self._run(src.contiguous(), src.shape[0], src.shape[2], src.shape[3], return_lowres)
 
     @torch.no_grad()
-    def forward_u8(self, frames, return_lowres=True, frame_keys=None, tri_batch=False):
+    def forward_u8(self, frames, return_lowres=True, frame_keys=None, tri_batch=False, pick_only=False):
         """frames: uint8 [N, H, W, 3] RGB on the GPU; /255 happens in the K1 kernel (same fp32 ops
         as the reference's host-side conversion), saving the 4x larger float upload.
 
@@ -251,7 +251,11 @@ class MOFNetHIP(_Holder):
         tri_batch (tri-frame networks, `--vf-architecture bof`): the N frames are B = N-2 overlapping triples
         (j-1, j, j+1) - B consecutive fields of a job in one pass, every centre frame its own problem; the
         output holds their 2B flows (forward flows first), field j's pick is flow B + j.  Same values as B
-        separate calls; at 720p one triple fills a third of the chip."""
+        separate calls; at 720p one triple fills a third of the chip.
+
+        pick_only (with return_lowres=False): return only the flow the reference takes from the output,
+        `[0, shape[1]//2]` = the backward flow of the first centre frame, as [1, 1, 2, H, W]; the last
+        iterations then skip the centre frames that can no longer influence it (same bits for that flow)."""
         if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8
                 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 [N,H,W,3] device tensor")
@@ -260,7 +264,7 @@ class MOFNetHIP(_Holder):
         if tri_batch and not self.tri_frame:
             raise ValueError("tri_batch applies to tri-frame (BOF) networks")
         return self._run(frames.contiguous(), frames.shape[0], frames.shape[1], frames.shape[2], return_lowres,
-                         frame_keys, tri_batch)
+                         frame_keys, tri_batch, pick_only and not return_lowres)
 
     # ------------------------------------------------------------------ per-frame encoder cache
     FEATURE_CACHE_FRAMES = 12
@@ -375,7 +379,7 @@ class MOFNetHIP(_Holder):
                     self._cache_put("c", keys[j], out[j])
         return out
 
-    def _run(self, src, N, H, W, return_lowres, frame_keys=None, tri_batch=False):
+    def _run(self, src, N, H, W, return_lowres, frame_keys=None, tri_batch=False, pick_only=False):
         cfg = self.cfg
         if N < 3:
             raise ValueError(f"need at least 3 frames, got {N}")
@@ -489,24 +493,31 @@ class MOFNetHIP(_Holder):
                               fmt_b=AF)
             ub = "update_block"
             for it in range(cfg.decoder_depth):
+                # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
+                # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
+                # more per iteration (through the temporal fusion), so the last iterations run on the centres
+                # that still matter only: GRU + flow head on `ng`, lookups + motion encoder on `nm` of them.
+                left = cfg.decoder_depth - 1 - it
+                ng = min(M, left + 1) if pick_only and not self.tri_frame else M
+                nm = min(M, left + 2) if pick_only and not self.tri_frame else M
                 # K5
-                hip.corr_lookup(pyrs["f"], hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF)
-                hip.corr_lookup(pyrs["b"], hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF)
+                hip.corr_lookup(pyrs["f"][:nm], hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF)
+                hip.corr_lookup(pyrs["b"][:nm], hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF)
                 # motion encoder
                 wgt, b = P[f"{ub}.encoder.convc1"]
-                hip.conv2d(corr, 2 * cor_p, 2 * cor_p, M, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
+                hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
                            in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convc2"]
-                hip.conv2d(c1, 256, 256, M, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+                hip.conv2d(c1, 256, 256, nm, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
                            in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convf1"]
-                hip.conv2d(flow4, 4, 4, M, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
                            out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.convf2"]
-                hip.conv2d(f1, 128, 128, M, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
+                hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.encoder.conv"]
-                hip.conv2d(cf, 256, 256, M, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
+                hip.conv2d(cf, 256, 256, nm, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # temporal stack fusion: 3x1 conv along the frame axis of the motion features
                 wgt, b = P[f"{ub}.tprop"]
@@ -514,39 +525,47 @@ class MOFNetHIP(_Holder):
                     hip.conv2d(G, 128, GLD, M, 1, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 else:
-                    hip.conv2d(G, 128, GLD, 1, M, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
+                    # (on the first nm frames: row nm-1 of a shortened stack sees zero padding where its lower
+                    # neighbour was - that row is not among the ng < nm the GRU reads)
+                    hip.conv2d(G, 128, GLD, 1, nm, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 # SepConvGRU, horizontal then vertical
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
                     # [z | r*h] = gates(conv([h | motion | temporal]) + context part)
-                    hip.conv2d(G, 128, GLD, M, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
+                    hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
                                in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
                                addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                     wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
                     # h = (1 - z) h + z tanh(conv([r*h | motion | temporal]) + context part), in place
-                    hip.conv2d(G, 128, GLD, M, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
+                    hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
                                in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
                                aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
                                in_fmt=AF, out_fmt=AF, aux_fmt=AF)
                 # flow head
                 wgt, b = P[f"{ub}.flow_head.conv1"]
-                hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                            epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
                 wgt, b = P[f"{ub}.flow_head.conv2"]
-                hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
-                hip.coords_update(coords1, delta, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
+                hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
                                   flow_b_off=MF + 124, fmt_b=AF)
 
-            # mask head on the final hidden state, then K8 for every flow of the output tensor
+            # mask head on the final hidden state, then K8 for every flow of the output tensor (pick_only: of
+            # the first centre frame, and its backward flow alone)
+            no = 1 if pick_only and not self.tri_frame else M
             mask = self._buf("mask", MP * 1152, dev)
             wgt, b = P[f"{ub}.mask.0"]
-            hip.conv2d(G, 128, GLD, M, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+            hip.conv2d(G, 128, GLD, no, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                        epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
             wgt, b = P[f"{ub}.mask.2"]
-            hip.conv2d(fh, 256, 256, M, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF)
+            hip.conv2d(fh, 256, 256, no, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF)
+            if pick_only and not self.tri_frame:
+                up = torch.empty(1, H, W, 2, device=dev, dtype=torch.float32)
+                hip.convex_upsample(coords1, 0, 2, mask, 576, 1152, h, w, up.view(-1))
+                return up.permute(0, 3, 1, 2).unsqueeze(0), None        # [1, 1, 2, H, W]: flow M of the full output
             up = torch.empty(2 * M, H, W, 2, device=dev, dtype=torch.float32)
             upf = up.view(-1)
             for d in range(2):
