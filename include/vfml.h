@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 8
+#define VFML_ABI_VERSION 9
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -192,6 +192,15 @@ int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld
  * bottom/right with weight 0.  flow: [h][w][2] f32, out: [(h+1)/2][(w+1)/2][2].  Same association as
  * the reference's per-block np.sum, divisions by 1, 2 or 4: bit-exact. */
 int vfml_flow_lod(const float* flow, int h, int w, float* out, void* stream);
+
+/* Flow field [h][w][2] f32 (pixels) -> 8-bit RGB image [h][w][3] as the reference's encoders produce it, byte for
+ * byte (encoding/flow_encoders.py: GamedevFlowEncoder :70-117, MotionVectorsRG8FlowEncoder :120-153,
+ * MotionVectorsRGB8FlowEncoder 'rgb+' :242-293).  gamedev: (flow / (width, height)) * scale, clamp, map to
+ * [0,1]; rg8: clamp, map; rgb8: direction / magnitude code.  clamp / two_clamp are float32(clamp_range) and
+ * float32(2 * clamp_range) (numpy promotes the Python floats that way).  SURVEY.md 8(f)-3. */
+enum { VFML_ENCODE_GAMEDEV = 0, VFML_ENCODE_RG8 = 1, VFML_ENCODE_RGB8 = 2 };
+int vfml_flow_encode(const float* flow, int h, int w, int mode, float width, float height, float scale,
+                     float clamp, float two_clamp, unsigned char* out, void* stream);
 
 const char* vfml_last_error(void);
 int vfml_abi_version(void);

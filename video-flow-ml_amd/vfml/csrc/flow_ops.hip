@@ -337,6 +337,76 @@ extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, cons
   return vfml_check_launch("vfml_corr_lookup");
 }
 
+// ---- flow -> 8-bit motion-vector images (reference encoding/flow_encoders.py) ---------------------------
+// Byte outputs: every float32 operation of the reference's numpy code is done as the same single
+// IEEE operation (correctly rounded divide and square root, no fused multiply-add), NaN / inf flow
+// through clip / nan_to_num exactly as numpy's minimum(maximum()) and astype(uint8) treat them.
+namespace {
+#pragma clang fp contract(off)
+__device__ __forceinline__ float np_clip(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
+// float32 square root, correctly rounded like numpy's: through the double-precision root (53 >= 2*24 + 2 bits:
+// the second rounding is innocuous); v_sqrt_f32 alone is 1 ulp off on ~2e-5 of the inputs
+__device__ __forceinline__ float np_sqrt(float x) { return (float)sqrt((double)x); }
+__device__ __forceinline__ unsigned char np_u8(float v) {      // nan_to_num(nan=0, posinf=255, neginf=0).astype(uint8)
+  if (v != v) return 0;
+  if (v == INFINITY) return 255;
+  if (v == -INFINITY) return 0;
+  return (unsigned char)(int)v;
+}
+
+struct EncodeArgs {
+  const float* flow; unsigned char* out; int64_t n;
+  int mode;                        // VFML_ENCODE_*
+  float width, height, scale;      // gamedev: divide by the image size, then scale
+  float clamp, two_clamp;          // float32(clamp_range), float32(2 * clamp_range)
+};
+
+__global__ void flow_encode_kernel(const EncodeArgs a) {
+#pragma clang fp contract(off)
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * blockDim.x) {
+    float fx = a.flow[2 * p], fy = a.flow[2 * p + 1];
+    unsigned char r, g, b;
+    if (a.mode == VFML_ENCODE_RGB8) {
+      float dx = fx / a.clamp, dy = fy / a.clamp;
+      const float len = np_sqrt(dx * dx + dy * dy);
+      if (len > 1.0f) {
+        dx = dx / len;
+        dy = dy / len;
+      }
+      const float corr = np_sqrt((1.0f - dx * dx) - dy * dy);
+      r = np_u8(((np_clip(dx, -1.0f, 1.0f) + 1.0f) / 2.0f) * 255.0f);
+      g = np_u8(((np_clip(dy, -1.0f, 1.0f) + 1.0f) / 2.0f) * 255.0f);
+      b = np_u8(corr * 255.0f);
+    } else {
+      if (a.mode == VFML_ENCODE_GAMEDEV) {
+        fx = (fx / a.width) * a.scale;
+        fy = (fy / a.height) * a.scale;
+      }
+      const float ex = np_clip((np_clip(fx, -a.clamp, a.clamp) + a.clamp) / a.two_clamp, 0.0f, 1.0f);
+      const float ey = np_clip((np_clip(fy, -a.clamp, a.clamp) + a.clamp) / a.two_clamp, 0.0f, 1.0f);
+      r = np_u8(ex * 255.0f);
+      g = np_u8(ey * 255.0f);
+      b = 0;
+    }
+    a.out[3 * p] = r;
+    a.out[3 * p + 1] = g;
+    a.out[3 * p + 2] = b;
+  }
+}
+}  // namespace
+
+extern "C" int vfml_flow_encode(const float* flow, int h, int w, int mode, float width, float height, float scale,
+                                float clamp, float two_clamp, unsigned char* out, void* stream) {
+  VFML_REQUIRE(flow && out && h > 0 && w > 0, "vfml_flow_encode: bad argument");
+  VFML_REQUIRE(mode == VFML_ENCODE_GAMEDEV || mode == VFML_ENCODE_RG8 || mode == VFML_ENCODE_RGB8,
+               "vfml_flow_encode: unknown mode %d", mode);
+  EncodeArgs a;
+  a.flow = flow; a.out = out; a.n = (int64_t)h * w; a.mode = mode;
+  a.width = width; a.height = height; a.scale = scale; a.clamp = clamp; a.two_clamp = two_clamp;
+  hipLaunchKernelGGL(flow_encode_kernel, dim3(grid_for(a.n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  return vfml_check_launch("vfml_flow_encode");
+}
+
 extern "C" int vfml_coords_init(float* coords1, int n, int h, int w, void* stream) {
   VFML_REQUIRE(coords1 && n > 0 && h > 0 && w > 0, "vfml_coords_init: bad argument");
   VFML_REQUIRE(vfml_aligned16(coords1), "vfml_coords_init: alignment");

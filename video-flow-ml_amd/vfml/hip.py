@@ -90,10 +90,12 @@ def lib():
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
     L.vfml_flow_lod.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    L.vfml_flow_encode.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p,
+                                   c_void_p]
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 8:
+    if L.vfml_abi_version() != 9:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -103,7 +105,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
-    "vfml_convex_upsample", "vfml_flow_lod", "vfml_last_error", "vfml_abi_version",
+    "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_last_error", "vfml_abi_version",
 ]
 
 
@@ -388,6 +390,22 @@ def flow_lods(flow, num_lods=5):
         _check(lib().vfml_flow_lod(_ptr(lods[-1]), h, w, _ptr(out), _stream()), "vfml_flow_lod")
         lods.append(out)
     return lods
+
+
+ENCODE_GAMEDEV, ENCODE_RG8, ENCODE_RGB8 = 0, 1, 2
+
+
+def flow_encode(flow, mode, clamp_range, width=1.0, height=1.0, scale=1.0):
+    """[H,W,2] float32 device tensor -> [H,W,3] uint8 device tensor (vfml_flow_encode)."""
+    import numpy as np
+    f = _dev(flow.contiguous())
+    h, w = f.shape[:2]
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=f.device)
+    _check(lib().vfml_flow_encode(_ptr(f), h, w, mode, float(np.float32(width)), float(np.float32(height)),
+                                  float(np.float32(scale)), float(np.float32(clamp_range)),
+                                  float(np.float32(2 * clamp_range)), c_void_p(out.data_ptr()), _stream()),
+           "vfml_flow_encode")
+    return out
 
 
 def convex_upsample(coords1, coords_off, ch, mask, mask_off, ld_mask, h, w, out, out_off=0):
