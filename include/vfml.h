@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 9
+#define VFML_ABI_VERSION 10
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -201,6 +201,22 @@ int vfml_flow_lod(const float* flow, int h, int w, float* out, void* stream);
 enum { VFML_ENCODE_GAMEDEV = 0, VFML_ENCODE_RG8 = 1, VFML_ENCODE_RGB8 = 2 };
 int vfml_flow_encode(const float* flow, int h, int w, int mode, float width, float height, float scale,
                      float clamp, float two_clamp, unsigned char* out, void* stream);
+
+/* One temporal-anti-aliasing step: blend the current frame into its history, the history reprojected along the flow
+ * field (reference effects/taa_processor.py: apply_taa :42-89, _apply_flow_based_taa :92-146,
+ * _bilateral_reprojection_sample :148-216, _bilinear_sample :218-263).  SURVEY.md 8(f)-3.
+ *   current: [h][w][3] u8 or f32 (0..255); flow: [h][w][2] f32, pixels, pointing from a pixel to where it was in the
+ *   history image (NULL in SIMPLE mode); history: [h][w][3] f32 or f64; out: [h][w][3], never the history buffer.
+ *   SIMPLE    out = alpha*current + (1-alpha)*history                         (out type = history type)
+ *   BILINEAR  history sampled bilinearly at (x, y) + flow, clamped to the image (out f32)
+ *   BILATERAL the four neighbours weighted by bilinear weight x exp(-(lum - lum_k)^2 / (0.2 sigma_color^2 + 1e-6)),
+ *             renormalised (out f64)
+ * Every intermediate has the dtype numpy's promotion gives it in the reference, so a sequence of steps tracks the
+ * reference's history to the last few ulps (exp() is the only step that is not reproduced bit for bit). */
+enum { VFML_TAA_SIMPLE = 0, VFML_TAA_BILINEAR = 1, VFML_TAA_BILATERAL = 2 };
+enum { VFML_PIX_U8 = 0, VFML_PIX_F32 = 1, VFML_PIX_F64 = 2 };
+int vfml_taa_blend(const void* current, int cur_type, const float* flow, const void* history, int hist_type,
+                   void* out, int out_type, int h, int w, int mode, double alpha, double sigma_color, void* stream);
 
 const char* vfml_last_error(void);
 int vfml_abi_version(void);

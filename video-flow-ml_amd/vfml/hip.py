@@ -7,14 +7,14 @@ if the library is missing or a kernel rejects its arguments this raises.
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFML_LIB") or os.path.join(_HERE, "libvfml_hip.so")   # VFML_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
 
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
@@ -92,10 +92,12 @@ def lib():
     L.vfml_flow_lod.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     L.vfml_flow_encode.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p,
                                    c_void_p]
+    L.vfml_taa_blend.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_double,
+                                 c_double, c_void_p]
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 9:
+    if L.vfml_abi_version() != 10:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -105,7 +107,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
-    "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_last_error", "vfml_abi_version",
+    "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_last_error", "vfml_abi_version",
 ]
 
 
@@ -405,6 +407,32 @@ def flow_encode(flow, mode, clamp_range, width=1.0, height=1.0, scale=1.0):
                                   float(np.float32(scale)), float(np.float32(clamp_range)),
                                   float(np.float32(2 * clamp_range)), c_void_p(out.data_ptr()), _stream()),
            "vfml_flow_encode")
+    return out
+
+
+TAA_SIMPLE, TAA_BILINEAR, TAA_BILATERAL = 0, 1, 2
+_PIX = {torch.uint8: 0, torch.float32: 1, torch.float64: 2}
+
+
+def taa_blend(current, flow, history, mode, alpha, sigma_color=25.0):
+    """One TAA step on the device (vfml_taa_blend): current [H,W,3] u8/f32, flow [H,W,2] f32 or None, history
+    [H,W,3] f32/f64 -> new history, in the dtype the reference's numpy arithmetic gives it."""
+    cur, hist = current.contiguous(), history.contiguous()
+    if not (cur.is_cuda and hist.is_cuda and cur.dtype in (torch.uint8, torch.float32)
+            and hist.dtype in (torch.float32, torch.float64)):
+        raise ValueError(f"taa_blend: device tensors u8/f32 + f32/f64 expected, got {cur.dtype} {hist.dtype}")
+    h, w = cur.shape[:2]
+    if tuple(cur.shape) != (h, w, 3) or tuple(hist.shape) != (h, w, 3):
+        raise ValueError(f"taa_blend: [H,W,3] images expected, got {tuple(cur.shape)} {tuple(hist.shape)}")
+    if mode != TAA_SIMPLE:
+        flow = _dev(flow.contiguous())
+        if tuple(flow.shape) != (h, w, 2):
+            raise ValueError(f"taa_blend: flow {tuple(flow.shape)} does not match the frame {h}x{w}")
+    out_dtype = hist.dtype if mode == TAA_SIMPLE else (torch.float32 if mode == TAA_BILINEAR else torch.float64)
+    out = torch.empty((h, w, 3), dtype=out_dtype, device=cur.device)
+    _check(lib().vfml_taa_blend(c_void_p(cur.data_ptr()), _PIX[cur.dtype], None if mode == TAA_SIMPLE else _ptr(flow),
+                                c_void_p(hist.data_ptr()), _PIX[hist.dtype], c_void_p(out.data_ptr()), _PIX[out_dtype],
+                                h, w, mode, float(alpha), float(sigma_color), _stream()), "vfml_taa_blend")
     return out
 
 
