@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 10
+#define VFML_ABI_VERSION 11
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -217,6 +217,15 @@ enum { VFML_TAA_SIMPLE = 0, VFML_TAA_BILINEAR = 1, VFML_TAA_BILATERAL = 2 };
 enum { VFML_PIX_U8 = 0, VFML_PIX_F32 = 1, VFML_PIX_F64 = 2 };
 int vfml_taa_blend(const void* current, int cur_type, const float* flow, const void* history, int hist_type,
                    void* out, int out_type, int h, int w, int mode, double alpha, double sigma_color, void* stream);
+
+/* Flow quality map (reference correction_worker.py: generate_quality_frame_gpu :175-208): how well frame2, warped
+ * back along the flow, matches frame1.  frame1, frame2, out: [h][w][3] u8; flow: [fh][fw][2] f32 at the frame's
+ * resolution or at a cached LOD's (then resized bilinearly, align_corners = False, and rescaled by w/fw, h/fh).
+ * Per pixel: target = (x, y) - flow, truncated to a texel; similarity = mean of (1 - |d|_2 / 1.732),
+ * (1 - mean |d|), (cos + 1) / 2 of the two colours in [0,1]; out = (0, 2 (s - 0.5), 0) * 255 if s > threshold else
+ * ((1 - s), 0, 0) * 255; (255, 0, 0) where the target is outside the image.  SURVEY.md 8(f)-4. */
+int vfml_flow_quality_map(const unsigned char* frame1, const unsigned char* frame2, const float* flow, int fh, int fw,
+                          int h, int w, float threshold, unsigned char* out, void* stream);
 
 const char* vfml_last_error(void);
 int vfml_abi_version(void);

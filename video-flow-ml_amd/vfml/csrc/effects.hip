@@ -158,3 +158,115 @@ extern "C" int vfml_taa_blend(const void* current, int cur_type, const float* fl
   else h64 ? launch_taa<VFML_TAA_BILATERAL, double>(a, u8, s) : launch_taa<VFML_TAA_BILATERAL, float>(a, u8, s);
   return vfml_check_launch("vfml_taa_blend");
 }
+
+// ---- flow quality map (reference correction_worker.py:175-208) -------------------------------------
+// One thread per pixel: warp frame 2 back along the flow (nearest texel by truncation), score the colour match with
+// frame 1 (RGB distance, mean absolute difference, cosine similarity), paint green above the threshold, red below,
+// full red where the vector leaves the image.  6 B + 8 B read, 3 B written per pixel.  Each float32 step is the single
+// IEEE operation torch's CPU kernels perform, fused multiply-adds included where torch has them (bilinear resize of
+// LOD fields, vector norms).
+namespace {
+
+struct QualityArgs {
+  const unsigned char* f1; const unsigned char* f2; const float* flow; unsigned char* out;
+  int h, w, fh, fw;
+  float scale_y, scale_x;     // fh / h, fw / w (float32 quotients): source step of the bilinear resize
+  float mul_x, mul_y;         // float32(w / fw), float32(h / fh): the vector rescale after it
+  float threshold;
+};
+
+__device__ __forceinline__ float root32(float x) { return (float)sqrt((double)x); }   // correctly rounded
+__device__ __forceinline__ float clamp01(float v) { return v != v ? v : fminf(fmaxf(v, 0.0f), 1.0f); }
+// float -> int64 -> clamp, with the host's result for NaN and out-of-range values (INT64_MIN, hence 0)
+__device__ __forceinline__ int texel(float t, int n) {
+  if (!(fabsf(t) < 9.0e18f)) return 0;
+  const long long i = (long long)t;
+  return (int)(i < 0 ? 0 : (i > n - 1 ? n - 1 : i));
+}
+// source taps of one output coordinate (align_corners = False)
+__device__ __forceinline__ void taps(int dst, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+  float src = fmaf(scale, (float)dst + 0.5f, -0.5f);
+  src = fmaxf(src, 0.0f);
+  i0 = min((int)floorf(src), n_in - 1);
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+  l0 = 1.0f - l1;
+}
+
+template <bool RESIZE>
+__global__ void quality_map_kernel(const QualityArgs a) {
+#pragma clang fp contract(off)
+  const int64_t n = (int64_t)a.h * a.w;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(p / a.w), x = (int)(p - (int64_t)y * a.w);
+    float fx, fy;
+    if constexpr (RESIZE) {
+      int y0, y1, x0, x1;
+      float hy0, hy1, wx0, wx1;
+      taps(y, a.scale_y, a.fh, y0, y1, hy0, hy1);
+      taps(x, a.scale_x, a.fw, x0, x1, wx0, wx1);
+      const float2* fl = (const float2*)a.flow;
+      const float2 v00 = fl[(int64_t)y0 * a.fw + x0], v01 = fl[(int64_t)y0 * a.fw + x1];
+      const float2 v10 = fl[(int64_t)y1 * a.fw + x0], v11 = fl[(int64_t)y1 * a.fw + x1];
+      fx = fmaf(fmaf(v00.x, wx0, v01.x * wx1), hy0, fmaf(v10.x, wx0, v11.x * wx1) * hy1) * a.mul_x;
+      fy = fmaf(fmaf(v00.y, wx0, v01.y * wx1), hy0, fmaf(v10.y, wx0, v11.y * wx1) * hy1) * a.mul_y;
+    } else {
+      const float2 v = ((const float2*)a.flow)[p];
+      fx = v.x;
+      fy = v.y;
+    }
+    const float tx = (float)x - fx, ty = (float)y - fy;
+    unsigned char r, g;
+    if (tx < 0.0f || tx >= (float)a.w || ty < 0.0f || ty >= (float)a.h) {
+      r = 255;
+      g = 0;
+    } else {
+      const unsigned char* q1 = a.f1 + 3 * p;
+      const unsigned char* q2 = a.f2 + 3 * ((int64_t)texel(ty, a.h) * a.w + texel(tx, a.w));
+      float s[3], t[3], d[3];
+      for (int c = 0; c < 3; ++c) {
+        s[c] = div32((float)q1[c], 255.0f);
+        t[c] = div32((float)q2[c], 255.0f);
+        d[c] = s[c] - t[c];
+      }
+      const float rgb = 1.0f - div32(root32((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1.732f);
+      const float mad = 1.0f - div32((fabsf(d[0]) + fabsf(d[1])) + fabsf(d[2]), 3.0f);
+      const float ns = fmaxf(root32(fmaf(s[2], s[2], fmaf(s[1], s[1], s[0] * s[0]))), 1e-8f);
+      const float nt = fmaxf(root32(fmaf(t[2], t[2], fmaf(t[1], t[1], t[0] * t[0]))), 1e-8f);
+      const float dot = (div32(s[0], ns) * div32(t[0], nt) + div32(s[1], ns) * div32(t[1], nt)) + div32(s[2], ns) * div32(t[2], nt);
+      const float cosine = div32(dot + 1.0f, 2.0f);
+      const float overall = div32((rgb + mad) + cosine, 3.0f);
+      if (overall > a.threshold) {
+        r = 0;
+        g = (unsigned char)(int)(clamp01((overall - 0.5f) * 2.0f) * 255.0f);
+      } else {
+        r = (unsigned char)(int)(clamp01(1.0f - overall) * 255.0f);
+        g = 0;
+      }
+    }
+    a.out[3 * p] = r;
+    a.out[3 * p + 1] = g;
+    a.out[3 * p + 2] = 0;
+  }
+}
+}  // namespace
+
+extern "C" int vfml_flow_quality_map(const unsigned char* frame1, const unsigned char* frame2, const float* flow, int fh,
+                                     int fw, int h, int w, float threshold, unsigned char* out, void* stream) {
+  VFML_REQUIRE(frame1 && frame2 && flow && out && h > 0 && w > 0 && fh > 0 && fw > 0, "vfml_flow_quality_map: bad argument");
+  VFML_REQUIRE((reinterpret_cast<uintptr_t>(flow) & 7u) == 0, "vfml_flow_quality_map: flow must be 8-byte aligned");
+  VFML_REQUIRE(h <= (1 << 24) && w <= (1 << 24), "vfml_flow_quality_map: image side above 2^24 (float32 pixel grid)");
+  QualityArgs a;
+  a.f1 = frame1; a.f2 = frame2; a.flow = flow; a.out = out;
+  a.h = h; a.w = w; a.fh = fh; a.fw = fw;
+  a.scale_y = (float)fh / (float)h;
+  a.scale_x = (float)fw / (float)w;
+  a.mul_x = (float)((double)w / (double)fw);
+  a.mul_y = (float)((double)h / (double)fh);
+  a.threshold = threshold;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(blocks_for((int64_t)h * w, 256)), block(256);
+  if (fh == h && fw == w) hipLaunchKernelGGL(quality_map_kernel<false>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(quality_map_kernel<true>, grid, block, 0, s, a);
+  return vfml_check_launch("vfml_flow_quality_map");
+}

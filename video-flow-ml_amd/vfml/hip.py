@@ -94,10 +94,11 @@ def lib():
                                    c_void_p]
     L.vfml_taa_blend.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_double,
                                  c_double, c_void_p]
+    L.vfml_flow_quality_map.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 10:
+    if L.vfml_abi_version() != 11:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -107,7 +108,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
-    "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_last_error", "vfml_abi_version",
+    "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
 
@@ -433,6 +434,18 @@ def taa_blend(current, flow, history, mode, alpha, sigma_color=25.0):
     _check(lib().vfml_taa_blend(c_void_p(cur.data_ptr()), _PIX[cur.dtype], None if mode == TAA_SIMPLE else _ptr(flow),
                                 c_void_p(hist.data_ptr()), _PIX[hist.dtype], c_void_p(out.data_ptr()), _PIX[out_dtype],
                                 h, w, mode, float(alpha), float(sigma_color), _stream()), "vfml_taa_blend")
+    return out
+
+
+def flow_quality_map(frame1, frame2, flow, threshold):
+    """uint8 frames [H,W,3] + flow [fh,fw,2] f32 (device tensors) -> uint8 quality map [H,W,3] (vfml_flow_quality_map)."""
+    f1, f2, fl = _dev(frame1.contiguous(), torch.uint8), _dev(frame2.contiguous(), torch.uint8), _dev(flow.contiguous())
+    h, w = f1.shape[:2]
+    if tuple(f1.shape) != (h, w, 3) or f2.shape != f1.shape or fl.dim() != 3 or fl.shape[2] != 2:
+        raise ValueError(f"flow_quality_map: frames {tuple(f1.shape)} {tuple(f2.shape)}, flow {tuple(fl.shape)}")
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=f1.device)
+    _check(lib().vfml_flow_quality_map(c_void_p(f1.data_ptr()), c_void_p(f2.data_ptr()), _ptr(fl), fl.shape[0], fl.shape[1],
+                                       h, w, float(threshold), c_void_p(out.data_ptr()), _stream()), "vfml_flow_quality_map")
     return out
 
 
