@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, 
 import torch
 from vfml import hip
 
-def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=False, cblock=None, gemm=False):
+def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=False, cblock=None, gemm=False, stride=1, f32_out=False):
     cblock = (os.environ.get("MB_CBLOCK", "1") == "1") if cblock is None else cblock
     ld = ld or cin
     x = torch.randn(n * h * w * ld, device="cuda")
@@ -30,8 +30,8 @@ def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=
         if gemm:     # as the correlation volume is built: no bias, no activation, plain f32 out
             hip.conv2d(x, cin, ld, n, h, w, wobj, None, cout, kh, kw, out, cout, out_scale=1.0 / 16.0, in_fmt=fmt)
         else:
-            hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
-                       in_fmt=fmt, out_fmt=fmt)
+            hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, stride=stride, pad_h=kh // 2, pad_w=kw // 2,
+                       epilogue=hip.EPI_NONE if f32_out else hip.EPI_RELU, in_fmt=fmt, out_fmt=hip.FMT_F32 if f32_out else fmt)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,8 +39,28 @@ def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = 2.0 * n * h * w * kh * kw * cin * cout
+    fl = 2.0 * n * ((h - 1) // stride + 1) * ((w - 1) // stride + 1) * kh * kw * cin * cout
     print(f"{name:46s} M={n*h*w:8d} K={kh*kw*cin:5d} cout={cout:5d}  {ms*1000:8.1f} us  {fl/ms/1e9:7.1f} TF/s")
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "enc":
+    # the residual-block convs of one 1080p frame's encoder: float32 rows split while staged (shipped) vs split rows
+    for s16 in (False, True):
+        bench("layer1 3x3 c64->64 540x960", 1, 540, 960, 64, 64, 3, 3, s16=s16, f32_out=True)
+        bench("layer2 3x3 c64->96 s2", 1, 540, 960, 64, 96, 3, 3, s16=s16, f32_out=True, stride=2)
+        bench("layer2 1x1 c64->96 s2", 1, 540, 960, 64, 96, 1, 1, s16=s16, f32_out=True, stride=2)
+        bench("layer2 3x3 c96->96 270x480", 1, 270, 480, 96, 96, 3, 3, s16=s16, f32_out=True)
+        bench("layer3 3x3 c96->128 s2", 1, 270, 480, 96, 128, 3, 3, s16=s16, f32_out=True, stride=2)
+        bench("layer3 3x3 c128->128 135x240", 1, 135, 240, 128, 128, 3, 3, s16=s16, f32_out=True)
+        bench("conv2 1x1 c128->256 135x240", 1, 135, 240, 128, 256, 1, 1, s16=s16, f32_out=True)
+    x = torch.randn(540 * 960 * 64, device="cuda"); y = torch.empty_like(x)
+    for _ in range(3): hip.to_s16(x, 540 * 960, 64, 64, y, 64)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): hip.to_s16(x, 540 * 960, 64, 64, y, 64)
+    e1.record(); torch.cuda.synchronize()
+    print(f"to_s16 540x960x64: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+    sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s16":
     bench("gru 1x5 c512->256", 3, 135, 240, 512, 256, 1, 5, s16=True)
