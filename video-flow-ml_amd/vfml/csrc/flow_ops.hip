@@ -10,7 +10,12 @@ constexpr int MAX_LEVELS = 6;
 constexpr int MAX_MAPS = 8;
 constexpr int MAX_RADIUS = 4;
 constexpr int PATCH = 2 * MAX_RADIUS + 2;  // 10 integer-grid samples per axis
-constexpr int LOOKUP_WAVES = 4;
+#ifndef VFML_LOOKUP_WAVES
+#define VFML_LOOKUP_WAVES 4
+#endif
+constexpr int LOOKUP_WAVES = VFML_LOOKUP_WAVES;
+constexpr int FIXED_LEVELS = 4;   // the fixed-radius kernel's pyramid depth limit (the networks use 4)
+static_assert(FIXED_LEVELS == 4, "corr_lookup_fixed_kernel selects among four levels");
 
 struct LookupArgs {
   const float* pyr[MAX_MAPS][MAX_LEVELS];   // one pyramid per query map (problem); rows = that map's queries
@@ -102,36 +107,61 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
 template <int R, bool OUT16>
 __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(const LookupArgs a) {
   constexpr int SIDE = 2 * R + 2, PSZ = SIDE * SIDE, WIN = 2 * R + 1, WW = WIN * WIN;
-  __shared__ float patch[LOOKUP_WAVES][MAX_LEVELS][PSZ];
-  __shared__ float frac[LOOKUP_WAVES][MAX_LEVELS][2];
+  __shared__ float patch[LOOKUP_WAVES][FIXED_LEVELS][PSZ];
+  __shared__ float frac[LOOKUP_WAVES][FIXED_LEVELS][2];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int q = blockIdx.x * LOOKUP_WAVES + wv;
   const bool live = q < a.nq;
-  const int map = live ? q / a.q_per_map : 0;
+  // the wave's query is uniform: pyramid pointers and level shapes come through scalar registers and are picked
+  // per lane with selects (a per-lane index into the kernel arguments would be a dependent memory load)
+  const int map = __builtin_amdgcn_readfirstlane(live ? q / a.q_per_map : 0);
   const int qq = q - map * a.q_per_map;
   if (live) {
     const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
     const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
     const int total = a.levels * PSZ;
-    for (int e = lane; e < total; e += 64) {
-      const int l = e / PSZ;
-      const int idx = e - l * PSZ;
-      const int py = idx / SIDE, px = idx - py * SIDE;
-      const float inv = 1.0f / (float)(1 << l);
-      const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
-      const float fx0 = floorf(x), fy0 = floorf(y);
-      const int x0 = (int)fminf(fmaxf(fx0, -65536.f), 65536.f) - R;
-      const int y0 = (int)fminf(fmaxf(fy0, -65536.f), 65536.f) - R;
-      const int xx = x0 + px, yy = y0 + py;
-      float v = 0.f;
-      if (xx >= 0 && xx < a.wl[l] && yy >= 0 && yy < a.hl[l])
-        v = a.pyr[map][l][(int64_t)qq * a.ld[l] + yy * a.wl[l] + xx];
-      patch[wv][l][idx] = v;
-      if (idx == 0) {
-        frac[wv][l][0] = x - fx0;
-        frac[wv][l][1] = y - fy0;
+    const float* lp[FIXED_LEVELS];
+    int lw[FIXED_LEVELS], lh[FIXED_LEVELS];
+#pragma unroll
+    for (int l = 0; l < FIXED_LEVELS; ++l) {
+      lp[l] = l < a.levels ? a.pyr[map][l] + (int64_t)qq * a.ld[l] : nullptr;
+      lw[l] = a.wl[l];
+      lh[l] = a.hl[l];
+    }
+    // all texels of the query are requested before the first one is used: NLOAD independent loads in flight per
+    // lane (a loop that stores each value to LDS before the next load pays the HBM latency NLOAD times)
+    constexpr int NLOAD = (FIXED_LEVELS * PSZ + 63) / 64;
+    float val[NLOAD];
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int e = lane + 64 * it;
+      val[it] = 0.f;
+      if (e < total) {
+        const int l = e / PSZ;
+        const int idx = e - l * PSZ;
+        const int py = idx / SIDE, px = idx - py * SIDE;
+        const float inv = 1.0f / (float)(1 << l);
+        const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
+        const int x0 = (int)fminf(fmaxf(floorf(x), -65536.f), 65536.f) - R;
+        const int y0 = (int)fminf(fmaxf(floorf(y), -65536.f), 65536.f) - R;
+        const int xx = x0 + px, yy = y0 + py;
+        const float* base = l == 0 ? lp[0] : (l == 1 ? lp[1] : (l == 2 ? lp[2] : lp[3]));
+        const int wl = l == 0 ? lw[0] : (l == 1 ? lw[1] : (l == 2 ? lw[2] : lw[3]));
+        const int hl = l == 0 ? lh[0] : (l == 1 ? lh[1] : (l == 2 ? lh[2] : lh[3]));
+        if (xx >= 0 && xx < wl && yy >= 0 && yy < hl) val[it] = base[yy * wl + xx];
       }
+    }
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      const int e = lane + 64 * it;
+      if (e < total) (&patch[wv][0][0])[e] = val[it];
+    }
+    if (lane < a.levels) {
+      const float inv = 1.0f / (float)(1 << lane);
+      const float x = cx * inv, y = cy * inv;
+      frac[wv][lane][0] = x - floorf(x);
+      frac[wv][lane][1] = y - floorf(y);
     }
   }
   __syncthreads();
@@ -325,10 +355,10 @@ extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, cons
   const dim3 grid((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), block(64 * LOOKUP_WAVES);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int generic = getenv("VFML_LOOKUP_GENERIC") ? atoi(getenv("VFML_LOOKUP_GENERIC")) : 0;
-  if (radius == 4 && !generic) {
+  if (radius == 4 && !generic && levels <= FIXED_LEVELS) {
     if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, false>), grid, block, 0, st, a);
-  } else if (radius == 3 && !generic) {
+  } else if (radius == 3 && !generic && levels <= FIXED_LEVELS) {
     if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, false>), grid, block, 0, st, a);
   } else {
