@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 11
+#define VFML_ABI_VERSION 12
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -120,11 +120,15 @@ int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, i
 int vfml_split_f16(const float* src, int64_t rows, int k, int ld, float scale, void* hi, void* lo, int kp,
                    void* stream);
 
-/* Row softmax: out[r][c] = exp(x[r][c] - max_r) / sum_r for c < cols, written as split rows
+/* Row softmax: out[r][c] = scale * exp(x[r][c] - max_r) / sum_r for c < cols, written as split rows
  * (VFML_FMT_S16) and zero-filled up to ld_out (ld_out % 8 == 0, ld_out >= cols).  x: f32 [rows][ld_in].
+ * scale (a power of two <= 2^15; the consumer divides it out through out_scale) keeps small probabilities out of
+ * the f16 subnormal range: a 1080p row has 32400 of them, 3e-5 on average, and unscaled every one would lose up to
+ * 6e-8 - 0.1 % of the row's mass.
  * Replaces: torch.softmax over the key axis of the attention scores (materialised:
  * with 288 GB of HBM the P x P score matrix of one frame simply stays resident). */
-int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out, void* stream);
+int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out, float scale,
+                          void* stream);
 
 /* src f32 [rows][c] (row stride ld) -> split-f16 planes of its TRANSPOSE times scale: hi/lo [c][kp],
  * kp >= rows, kp % 32 == 0, zero padded: the "weight" operand of out = attn . V. */

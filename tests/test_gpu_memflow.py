@@ -1,6 +1,7 @@
 """MemFlow pair path (BASELINE config C4) against its CPU oracle, and the new
 entry points it needs (row softmax into split rows, transposed split planes, residual-add epilogue)."""
 import math
+import os
 
 import pytest
 import torch
@@ -39,6 +40,25 @@ def test_memflow_forward_matches_oracle(gpu, precision):
     assert (low.cpu() - low_ref).abs().max().item() < 1e-3
 
 
+def test_memflow_1080p_matches_oracle(gpu):
+    """One pair at the size of BASELINE config C4: 32400 keys per attention row - the probabilities average 3e-5,
+    which is where their storage scale (memflow_net.ATT_SCALE) matters."""
+    import time
+    net, ora = _pair()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    x = torch.rand(1, 2, 3, 1080, 1920, generator=torch.Generator().manual_seed(8)) * 2 - 1
+    x = torch.nn.functional.avg_pool2d(x[0], 9, 1, 4)[None]          # some structure for the matcher
+    t0 = time.time()
+    with torch.no_grad():
+        _, ref = ora(x)
+    dt = time.time() - t0
+    _, got = net(x.cuda())
+    epe = (got.cpu() - ref).pow(2).sum(1).sqrt()
+    print(f"[memflow 1080p] mean EPE {epe.mean().item():.3e} px, max {epe.max().item():.3e}, |flow| {ref.abs().mean().item():.2f}, "
+          f"oracle {dt:.0f} s")
+    assert epe.mean().item() < EPE_TOL
+
+
 def test_readout_changes_the_flow(gpu):
     """gamma = 0 switches the memory read-out off: the result must differ from gamma = 0.5 (the read-out
     path is live) and still match its own oracle."""
@@ -66,6 +86,18 @@ def test_softmax_rows_and_transposed_planes(gpu):
     ref = torch.softmax(x[:, :cols].double(), dim=-1).float()
     assert (got[:, cols:] == 0).all()
     assert (got[:, :cols] - ref).abs().max().item() < 5e-7   # 22-bit split rows
+    # the 1080p attention row (register-resident kernel, 16-byte loads), an input stride that forbids them, and a
+    # row too long for the registers (three-sweep kernel)
+    for rows, cols, ld, ldo in ((5, 32400, 32416, 32416), (7, 1001, 1003, 1008), (3, 40000, 40000, 40000)):
+        x = torch.randn(rows, ld, generator=g) * 3
+        ref = torch.softmax(x[:, :cols].double(), dim=-1)
+        for scale, rel, floor in ((16384.0, 2e-6, 1e-11), (1.0, 2e-6, 7e-8)):    # unscaled: f16 subnormal steps of 6e-8
+            out = torch.full((rows * ldo,), 9.0, device=gpu)
+            hip.softmax_rows_s16(x.cuda().reshape(-1), rows, cols, ld, out, ldo, scale=scale)
+            got = s16_decode(out, rows, ldo, ldo).double() / scale
+            assert (got[:, cols:] == 0).all()
+            assert ((got[:, :cols] - ref).abs() <= rel * ref + floor).all(), (rows, cols, scale)
+        assert (got[:, :cols].sum(dim=1) - 1).abs().max().item() < 2e-3    # unscaled rows lose mass to truncation
     v = torch.randn(50, 24, generator=g)
     sw = hip.SplitWeight(24, 50, gpu).fill_transposed(v.cuda().reshape(-1), 50, ld=24, scale=4.0)
     rec = (sw.hi.view(24, sw.kp).float() + sw.lo.view(24, sw.kp).float()).cpu() / 4.0

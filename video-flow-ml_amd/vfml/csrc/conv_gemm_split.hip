@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
 
 // one workgroup per row; three sweeps (max, sum of exp, write) over a row that stays in L2
 __global__ __launch_bounds__(256) void softmax_rows_s16_kernel(const float* __restrict__ x, int cols, int64_t ld_in,
-                                                               float* __restrict__ out, int64_t ld_out) {
+                                                               float* __restrict__ out, int64_t ld_out, float scale) {
   __shared__ float red[4];
   const float* row = x + (int64_t)blockIdx.x * ld_in;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_kernel(const float* __re
   if (lane == 0) red[wv] = s;
   __syncthreads();
   s = (red[0] + red[1]) + (red[2] + red[3]);
-  const float inv = 1.0f / s;
+  const float inv = scale / s;
   float* orow = out + (int64_t)blockIdx.x * ld_out;
   const int nq = (int)(ld_out / 4);
   for (int q4 = t; q4 < nq; q4 += 256) {
@@ -1107,6 +1107,69 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_kernel(const float* __re
     char* u = reinterpret_cast<char*>(orow + (c & ~7)) + (c & 4) * 2;
     *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hh.v, hh.v, 0, 1, 2, 3));
     *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(ll.v, ll.v, 0, 1, 2, 3));
+  }
+}
+
+// The same for rows of at most 256 * 4 * SOFTMAX_REG_QUADS columns: the row is read once (16-byte loads, all in
+// flight together) and stays in registers for the max, the sum of exp and the write - one exp per element instead
+// of two, no second and third sweep through L2.
+constexpr int SOFTMAX_REG_QUADS = 32;
+__global__ __launch_bounds__(256) void softmax_rows_s16_reg_kernel(const float* __restrict__ x, int cols, int64_t ld_in,
+                                                                   float* __restrict__ out, int64_t ld_out, float scale) {
+  __shared__ float red[4];
+  const float* row = x + (int64_t)blockIdx.x * ld_in;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const bool vec = (ld_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+  f32x4 v[SOFTMAX_REG_QUADS];
+#pragma unroll
+  for (int i = 0; i < SOFTMAX_REG_QUADS; ++i) {
+    const int c = (t + 256 * i) * 4;
+    if (vec && c + 3 < cols) {
+      v[i] = *reinterpret_cast<const f32x4*>(row + c);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = c + e < cols ? row[c + e] : -INFINITY;
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SOFTMAX_REG_QUADS; ++i) m = fmaxf(fmaxf(fmaxf(m, v[i][0]), fmaxf(v[i][1], v[i][2])), v[i][3]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SOFTMAX_REG_QUADS; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = expf(v[i][e] - m);          // exp(-inf) = 0 past the row's end
+      s += v[i][e];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = scale / s;
+  float* orow = out + (int64_t)blockIdx.x * ld_out;
+#pragma unroll
+  for (int i = 0; i < SOFTMAX_REG_QUADS; ++i) {
+    const int c = (t + 256 * i) * 4;
+    if (c < ld_out) {
+      U8 hh, ll;
+      split4(v[i] * inv, hh, ll, 0);
+#ifdef VFML_EXPERIMENT_ATT_HI_ONLY   // precision experiment: probabilities as one round-to-nearest f16
+      {
+        const f32x4 pv = v[i] * inv;
+        for (int e = 0; e < 4; ++e) { hh.v[e] = (_Float16)pv[e]; ll.v[e] = (_Float16)0.f; }
+      }
+#endif
+      char* u = reinterpret_cast<char*>(orow + (c & ~7)) + (c & 4) * 2;
+      *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hh.v, hh.v, 0, 1, 2, 3));
+      *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(ll.v, ll.v, 0, 1, 2, 3));
+    }
   }
 }
 
@@ -1123,12 +1186,18 @@ extern "C" int vfml_transpose_split_f16(const float* src, int rows, int c, int l
 }
 
 extern "C" int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out,
-                                     void* stream) {
+                                     float scale, void* stream) {
+  VFML_REQUIRE(scale >= 1.0f && scale <= 32768.0f, "vfml_softmax_rows_s16: scale %g out of [1, 2^15]", (double)scale);
   VFML_REQUIRE(x && out && rows > 0 && rows < (1ll << 31) && cols > 0 && ld_in >= cols && ld_out >= cols && ld_out % 8 == 0,
                "vfml_softmax_rows_s16: bad shape (ld_out %% 8 == 0, ld_out >= cols)");
   VFML_REQUIRE((reinterpret_cast<uintptr_t>(out) & 31u) == 0, "vfml_softmax_rows_s16: out must be 32-byte aligned");
-  hipLaunchKernelGGL(softmax_rows_s16_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     cols, ld_in, out, ld_out);
+  static const int sweep = getenv("VFML_SOFTMAX_SWEEPS") ? atoi(getenv("VFML_SOFTMAX_SWEEPS")) : 0;
+  if (ld_out <= 256 * 4 * SOFTMAX_REG_QUADS && !sweep)
+    hipLaunchKernelGGL(softmax_rows_s16_reg_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, cols, ld_in, out, ld_out, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_s16_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                       cols, ld_in, out, ld_out, scale);
   return vfml_check_launch("vfml_softmax_rows_s16");
 }
 

@@ -75,7 +75,7 @@ def lib():
     L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int,
                                     c_void_p]
     L.vfml_to_s16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]
-    L.vfml_softmax_rows_s16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_void_p]
+    L.vfml_softmax_rows_s16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_float, c_void_p]
     L.vfml_transpose_split_f16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_frames_to_nhwc4.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]
@@ -98,7 +98,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 11:
+    if L.vfml_abi_version() != 12:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -336,10 +336,10 @@ def avgpool2x2(x, n, h, w, c, out):
     _check(lib().vfml_avgpool2x2(_ptr(_dev(x)), n, h, w, c, _ptr(_dev(out)), _stream()), "vfml_avgpool2x2")
 
 
-def softmax_rows_s16(x, rows, cols, ld_in, out, ld_out, x_off=0, out_off=0):
-    """Row softmax of f32 scores -> split rows (FMT_S16), zero-filled to ld_out."""
+def softmax_rows_s16(x, rows, cols, ld_in, out, ld_out, x_off=0, out_off=0, scale=1.0):
+    """scale * row softmax of f32 scores -> split rows (FMT_S16), zero-filled to ld_out."""
     _check(lib().vfml_softmax_rows_s16(_ptr(_dev(x), x_off), rows, cols, ld_in, _ptr(_dev(out), out_off), ld_out,
-                                       _stream()), "vfml_softmax_rows_s16")
+                                       float(scale), _stream()), "vfml_softmax_rows_s16")
 
 
 def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):
