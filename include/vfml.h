@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 12
+#define VFML_ABI_VERSION 13
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -77,6 +77,12 @@ typedef struct vfml_conv_desc {
                                                        pair (a, b) read the other way round is the volume of
                                                        (b, a): one pass of MFMAs, two stores             */
   int32_t flags;                                    /* VFML_CONV_* bits (vfml_conv2d_split)               */
+  double* stats_part;                               /* optional (vfml_conv2d_split, f32 sources): per 128-pixel row
+                                                       tile and output channel, the sum and the sum of squares
+                                                       of the stored result, [n][ceil(hw/128)][cout][2] doubles
+                                                       (hw = output pixels per image; n == 1 or hw % 128 == 0):
+                                                       the first pass of vfml_instnorm_stats done where the tile
+                                                       still is in LDS; fold with vfml_instnorm_finalize      */
 } vfml_conv_desc;
 
 /* flags: accumulate the two cross terms of the split product in the order (a_lo*b_hi, a_hi*b_lo) instead of
@@ -190,6 +196,10 @@ int vfml_coords_init(float* coords1, int n, int h, int w, void* stream);
  * processing/videoflow_processor.py:185. */
 int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld_mask,
                          int h, int w, float* out, void* stream);
+
+/* Second pass of vfml_instnorm_stats on partial sums a convolution left behind (vfml_conv_desc.stats_part):
+ * part [n][chunks][c][2] doubles -> stats [n][c][2] = {mean, 1/sqrt(var + eps)}, folded in a fixed order. */
+int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats, void* stream);
 
 /* One level of the flow-cache LOD pyramid (reference storage/cache_manager.py:77-161): out[y][x] =
  * 0.5 * (sum of the 2x2 block's in-image vectors) / (number of in-image cells); odd sides are padded

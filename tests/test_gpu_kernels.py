@@ -493,6 +493,53 @@ def test_instnorm(gpu, c, hw):
     assert rel_err(from_nhwc(out, n, hw, 1, c), F.relu(F.instance_norm(res) + y)) < 3e-6
 
 
+@pytest.mark.parametrize("n,cin,cout,k,stride,H,W", [(1, 64, 64, 3, 1, 37, 53), (1, 4, 64, 7, 2, 70, 90), (1, 64, 96, 3, 2, 61, 45),
+                                                     (2, 96, 96, 3, 1, 16, 24), (1, 64, 96, 1, 2, 50, 38), (3, 128, 128, 3, 1, 8, 16)])
+def test_conv_leaves_instnorm_partials(gpu, n, cin, cout, k, stride, H, W):
+    """conv2d(stats_part=...) + instnorm_finalize == conv2d + instnorm_stats on the stored result (the encoder's
+    fused path): ragged last row tile, column tiles that end inside a tile, several images with whole tiles each."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(n * 1000 + cout + k)
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    pad = k // 2
+    ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    hw = ho * wo
+    wobj = as_weight(wt.permute(0, 2, 3, 1).reshape(-1).to(gpu), cout, "f16x3")
+    out_a = torch.empty(n * hw * cout, device=gpu)
+    out_b = torch.empty_like(out_a)
+    chunks = (hw + 127) // 128
+    part = torch.full((n * chunks * cout * 2 + 8,), float("nan"), device=gpu, dtype=torch.float64)
+    xd = nhwc(x)
+    hip.conv2d(xd, cin, cin, n, H, W, wobj, b.to(gpu), cout, k, k, out_a, cout, stride=stride, pad_h=pad, pad_w=pad,
+               stats_part=part)
+    hip.conv2d(xd, cin, cin, n, H, W, wobj, b.to(gpu), cout, k, k, out_b, cout, stride=stride, pad_h=pad, pad_w=pad)
+    assert torch.equal(out_a, out_b)
+    assert torch.isnan(part[n * chunks * cout * 2:]).all() and not torch.isnan(part[:n * chunks * cout * 2]).any()
+    st_a = torch.empty(n * cout * 2, device=gpu)
+    st_b = torch.empty_like(st_a)
+    hip.instnorm_finalize(part, n, chunks, cout, hw, st_a)
+    ws = torch.empty(hip.instnorm_workspace_bytes(n, hw, cout) // 8 + 1, device=gpu, dtype=torch.float64)
+    hip.instnorm_stats(out_b, n, hw, cout, st_b, ws)
+    assert torch.allclose(st_a, st_b, rtol=2e-7, atol=1e-9), (st_a - st_b).abs().max().item()
+    ref = from_nhwc(out_b, n, ho, wo, cout).double()
+    assert torch.allclose(st_a.view(n, cout, 2)[..., 0].cpu().double(), ref.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+
+
+def test_conv_stats_partials_reject_straddling_tiles(gpu):
+    from vfml import hip
+    x = torch.zeros(2 * 10 * 10 * 64, device=gpu)
+    wobj = as_weight(torch.zeros(64 * 9 * 64, device=gpu) + 0.01, 64, "f16x3")
+    out = torch.empty(2 * 100 * 64, device=gpu)
+    part = torch.empty(2 * 1 * 64 * 2, device=gpu, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="straddle"):
+        hip.conv2d(x, 64, 64, 2, 10, 10, wobj, None, 64, 3, 3, out, 64, pad_h=1, pad_w=1, stats_part=part)
+    with pytest.raises(RuntimeError, match="stats_part"):
+        hip.conv2d(x, 64, 64, 1, 10, 10, torch.zeros(64 * 9 * 64, device=gpu), None, 64, 3, 3, out, 64, pad_h=1, pad_w=1,
+                   stats_part=part)
+
+
 def test_avgpool2x2_floor(gpu):
     from vfml import hip
     g = torch.Generator().manual_seed(6)

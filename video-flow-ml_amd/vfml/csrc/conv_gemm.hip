@@ -240,6 +240,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
 extern "C" int vfml_conv2d(const vfml_conv_desc* d, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d: null descriptor");
   VFML_REQUIRE(d->out_t == nullptr && d->flags == 0, "vfml_conv2d: out_t / flags are vfml_conv2d_split (GEMM form) features");
+  VFML_REQUIRE(d->stats_part == nullptr, "vfml_conv2d: stats_part is a vfml_conv2d_split feature");
   VFML_REQUIRE(d->in0 && d->weight && d->out, "vfml_conv2d: null in0/weight/out");
   VFML_REQUIRE(d->c0 > 0 && d->c0 % 4 == 0 && d->ld0 % 4 == 0 && d->ld0 >= d->c0,
                "vfml_conv2d: c0=%d ld0=%d must be multiples of 4 with ld0>=c0", d->c0, d->ld0);

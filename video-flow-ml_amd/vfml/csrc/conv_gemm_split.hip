@@ -78,6 +78,7 @@ struct SplitArgs {
   int tilebase;   // 1x1 over one source: the source descriptor starts at the tile's first row (sources > 2 GiB)
   float* out_t; int ld_out_t;   // GEMM form: transposed second output (or null)
   int cswap;                    // VFML_CONV_SWAP_CROSS
+  double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -491,6 +492,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
   acc_to_lds<TM, TN, LDC>(acc, sC, wm * (BM / WM), wn * (BN / WN), r, half);
   __syncthreads();
   epilogue_rows<BN, NT>(a, sC, m0, n0, t);
+  if (a.stats_part) {
+    // instance-norm statistics of the tile while it is in LDS: thread = (channel, row group), doubles like the
+    // stand-alone pass; the value is the stored one (same expression as epilogue_rows, no addend / activation here)
+    constexpr int RG = NT / BN;            // row groups
+    const int ch = t % BN, rg = t / BN;
+    double s1 = 0.0, s2 = 0.0;
+    if (n0 + ch < a.cout) {
+      const float b = a.bias ? a.bias[n0 + ch] : 0.f;
+      for (int row = rg; row < BM; row += RG) {
+        if (m0 + row >= a.M) break;
+        const double v = (double)((sC[row * LDC + ch] * a.w_inv + b) * a.out_scale);
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    __syncthreads();                       // every thread is done with the tile: reuse it for the fold
+    double* fold = reinterpret_cast<double*>(sC);
+    fold[(rg * BN + ch) * 2] = s1;
+    fold[(rg * BN + ch) * 2 + 1] = s2;
+    __syncthreads();
+    if (rg == 0 && n0 + ch < a.cout) {
+      for (int g = 1; g < RG; ++g) {
+        s1 += fold[(g * BN + ch) * 2];
+        s2 += fold[(g * BN + ch) * 2 + 1];
+      }
+      double* o = a.stats_part + ((int64_t)(m0 / BM) * a.cout + n0 + ch) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
 }
 
 // ---- LDS-DMA variant (split-row sources, 128 x BN tile) ------------------------------------------
@@ -1233,6 +1264,13 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE((d->flags & ~VFML_CONV_SWAP_CROSS) == 0, "vfml_conv2d_split: unknown flag bits");
   VFML_REQUIRE(in_fmt == VFML_FMT_S16 || (d->flags == 0 && d->out_t == nullptr),
                "vfml_conv2d_split: out_t / flags need split-row sources");
+  if (d->stats_part) {
+    const int64_t hw_out = (int64_t)((d->h + 2 * d->pad_h - d->kh) / d->stride + 1) * ((d->w + 2 * d->pad_w - d->kw) / d->stride + 1);
+    VFML_REQUIRE(in_fmt == VFML_FMT_F32 && out_fmt == VFML_FMT_F32 && d->epilogue == VFML_EPI_NONE && !d->addend &&
+                 (d->n == 1 || hw_out % BM == 0) && (reinterpret_cast<uintptr_t>(d->stats_part) & 7u) == 0,
+                 "vfml_conv2d_split: stats_part needs f32 sources and output, no epilogue / addend, and row tiles that do "
+                 "not straddle images (n == 1 or output pixels per image %% 128 == 0)");
+  }
   VFML_REQUIRE(k_order == VFML_KORDER_TAP || (k_order == VFML_KORDER_CBLOCK && in_fmt == VFML_FMT_S16),
                "vfml_conv2d_split: bad k_order (channel-block order needs split-row sources)");
   VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
@@ -1295,6 +1333,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
 
   SplitArgs a;
   a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0;
+  a.stats_part = d->stats_part;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;

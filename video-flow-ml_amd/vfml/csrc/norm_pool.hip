@@ -88,26 +88,37 @@ __global__ __launch_bounds__(STAT_THREADS) void instnorm_partial_kernel(const fl
   }
 }
 
-// One wave per (n, channel): lanes stride over the chunk partials, then lane 0 folds the 64 lane sums
-// in lane order (fixed association -> bitwise reproducible).
-__global__ __launch_bounds__(64) void instnorm_final_kernel(const double* __restrict__ part, int n, int chunks, int c,
-                                                           int hw, float eps, float* __restrict__ stats) {
-  __shared__ double sh[64][2];
+// One workgroup per (n, channel): threads stride over the chunk partials (four independent loads in flight each),
+// then thread 0 folds the FINAL_THREADS sums in thread order (fixed association -> bitwise reproducible).
+constexpr int FINAL_THREADS = 256;
+__global__ __launch_bounds__(FINAL_THREADS) void instnorm_final_kernel(const double* __restrict__ part, int n, int chunks,
+                                                                      int c, int hw, float eps, float* __restrict__ stats) {
+  __shared__ double sh[FINAL_THREADS][2];
   const int i = blockIdx.x;   // n * c blocks
   const int nn = i / c, ch = i - nn * c;
-  const int lane = threadIdx.x;
+  const int t = threadIdx.x;
+  const double* base = part + ((int64_t)nn * chunks * c + ch) * 2;
   double s = 0, q = 0;
-  for (int k = lane; k < chunks; k += 64) {
-    const double* p = part + (((int64_t)nn * chunks + k) * c + ch) * 2;
+  int k = t;
+  for (; k + 3 * FINAL_THREADS < chunks; k += 4 * FINAL_THREADS) {
+    const double* p0 = base + (int64_t)k * c * 2;
+    const double* p1 = p0 + (int64_t)FINAL_THREADS * c * 2;
+    const double* p2 = p1 + (int64_t)FINAL_THREADS * c * 2;
+    const double* p3 = p2 + (int64_t)FINAL_THREADS * c * 2;
+    const double a0 = p0[0], b0 = p0[1], a1 = p1[0], b1 = p1[1], a2 = p2[0], b2 = p2[1], a3 = p3[0], b3 = p3[1];
+    s += a0; q += b0; s += a1; q += b1; s += a2; q += b2; s += a3; q += b3;
+  }
+  for (; k < chunks; k += FINAL_THREADS) {
+    const double* p = base + (int64_t)k * c * 2;
     s += p[0];
     q += p[1];
   }
-  sh[lane][0] = s;
-  sh[lane][1] = q;
+  sh[t][0] = s;
+  sh[t][1] = q;
   __syncthreads();
-  if (lane == 0) {
+  if (t == 0) {
     double ss = 0, qq = 0;
-    for (int l = 0; l < 64; ++l) {
+    for (int l = 0; l < FINAL_THREADS; ++l) {
       ss += sh[l][0];
       qq += sh[l][1];
     }
@@ -217,9 +228,17 @@ extern "C" int vfml_instnorm_stats(const float* x, int n, int hw, int c, float e
                      (double*)workspace);
   int rc = vfml_check_launch("vfml_instnorm_stats(partial)");
   if (rc) return rc;
-  hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(64), 0, s, (const double*)workspace, n, chunks, c, hw,
+  hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, s, (const double*)workspace, n, chunks, c, hw,
                      eps, stats);
   return vfml_check_launch("vfml_instnorm_stats(final)");
+}
+
+extern "C" int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats,
+                                      void* stream) {
+  VFML_REQUIRE(part && stats && n > 0 && chunks > 0 && c > 0 && hw > 0, "vfml_instnorm_finalize: bad argument");
+  hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, reinterpret_cast<hipStream_t>(stream), part, n, chunks,
+                     c, hw, eps, stats);
+  return vfml_check_launch("vfml_instnorm_finalize");
 }
 
 extern "C" int vfml_instnorm_apply(const float* x, const float* stats, const float* res, const float* res_stats, int n,

@@ -38,6 +38,7 @@ class ConvDesc(ctypes.Structure):
         ("addend", c_void_p), ("ld_addend", c_int32),
         ("out_t", c_void_p), ("ld_out_t", c_int32),
         ("flags", c_int32),
+        ("stats_part", c_void_p),
     ]
 
 
@@ -82,6 +83,7 @@ def lib():
     L.vfml_instnorm_workspace_bytes.restype = c_int64
     L.vfml_instnorm_workspace_bytes.argtypes = [c_int, c_int, c_int]
     L.vfml_instnorm_stats.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]
+    L.vfml_instnorm_finalize.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
@@ -98,7 +100,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 12:
+    if L.vfml_abi_version() != 13:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -107,7 +109,7 @@ def lib():
 EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
-    "vfml_instnorm_apply", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
+    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
     "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -253,7 +255,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
-           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False):
+           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers)."""
     d = ConvDesc()
@@ -271,6 +273,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.addend, d.ld_addend = (_ptr(_dev(addend), addend_off) if addend is not None else None), ld_addend
     d.out_t, d.ld_out_t = (_ptr(_dev(out_t), out_t_off) if out_t is not None else None), ld_out_t
     d.flags = CONV_SWAP_CROSS if swap_cross else 0
+    d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
         def launch():
@@ -325,6 +328,12 @@ def instnorm_workspace_bytes(n, hw, c):
 def instnorm_stats(x, n, hw, c, stats, workspace, eps=1e-5):
     _check(lib().vfml_instnorm_stats(_ptr(_dev(x)), n, hw, c, eps, _ptr(_dev(stats)),
                                      c_void_p(workspace.data_ptr()), _stream()), "vfml_instnorm_stats")
+
+
+def instnorm_finalize(part, n, chunks, c, hw, stats, eps=1e-5):
+    """Fold the partial sums a convolution left in `part` (conv2d(..., stats_part=part)) into {mean, rstd}."""
+    _check(lib().vfml_instnorm_finalize(c_void_p(part.data_ptr()), n, chunks, c, hw, eps, _ptr(_dev(stats)), _stream()),
+           "vfml_instnorm_finalize")
 
 
 def instnorm_apply(x, stats, n, hw, c, out, res=None, res_stats=None):

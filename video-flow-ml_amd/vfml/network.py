@@ -186,9 +186,31 @@ class MOFNetHIP(_Holder):
             hip.instnorm_stats(t, n, hw, c, s, ws)
             return s
 
-        wgt, b = P[f"{prefix}.conv1"]
-        hip.conv2d(x, 4, 4, n, H, W, wgt, b, 64, 7, 7, raw, 64, stride=2, pad_h=3, pad_w=3)
-        s0 = stats_of(raw, h2 * w2, 64, 0)
+        # split-f16 path: the convolution leaves per-tile sums behind (its tile is in LDS anyway) and only the fold
+        # remains; row tiles of 128 pixels must not straddle frames
+        split_prec = self._precision() == "f16x3"
+        part_len = n * ((h2 * w2 + 127) // 128) * 128 * 2          # largest layer: half resolution
+        parts = self._buf("enc_part", 3 * part_len, dev, torch.float64) if split_prec else None
+
+        def fused(hw):
+            return split_prec and (n == 1 or hw % 128 == 0)
+
+        def conv_stats(src, c, hh_, ww_, name, planes, dst, slot, k, stride=1, pad=0):
+            wgt, b = P[name]
+            ho_, wo_ = (hh_ + 2 * pad - k) // stride + 1, (ww_ + 2 * pad - k) // stride + 1
+            hw = ho_ * wo_
+            if not fused(hw):
+                hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad)
+                return stats_of(dst, hw, planes, slot)
+            chunks = (hw + 127) // 128
+            part = parts[slot * part_len:]
+            hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
+                       stats_part=part)
+            s = st[slot * n * 128 * 2:]
+            hip.instnorm_finalize(part, n, chunks, planes, hw, s)
+            return s
+
+        s0 = conv_stats(x, 4, H, W, f"{prefix}.conv1", 64, raw, 0, 7, stride=2, pad=3)
         cur = act[0]
         hip.instnorm_apply(raw, s0, n, h2 * w2, 64, cur)
         ch, hh, ww, ci = 64, h2, w2, 0
@@ -199,17 +221,11 @@ class MOFNetHIP(_Holder):
                 name = f"{prefix}.layer{li}.{bi}"
                 y = act[(ci + 1) % 3]
                 nxt = act[(ci + 2) % 3]
-                wgt, b = P[f"{name}.conv1"]
-                hip.conv2d(cur, ch, ch, n, hh, ww, wgt, b, planes, 3, 3, raw, planes, stride=stv, pad_h=1, pad_w=1)
-                s1 = stats_of(raw, ho * wo, planes, 0)
+                s1 = conv_stats(cur, ch, hh, ww, f"{name}.conv1", planes, raw, 0, 3, stride=stv, pad=1)
                 hip.instnorm_apply(raw, s1, n, ho * wo, planes, y)
-                wgt, b = P[f"{name}.conv2"]
-                hip.conv2d(y, planes, planes, n, ho, wo, wgt, b, planes, 3, 3, raw, planes, pad_h=1, pad_w=1)
-                s2 = stats_of(raw, ho * wo, planes, 1)
+                s2 = conv_stats(y, planes, ho, wo, f"{name}.conv2", planes, raw, 1, 3, pad=1)
                 if stv != 1:
-                    wgt, b = P[f"{name}.downsample.0"]
-                    hip.conv2d(cur, ch, ch, n, hh, ww, wgt, b, planes, 1, 1, raw2, planes, stride=stv)
-                    s3 = stats_of(raw2, ho * wo, planes, 2)
+                    s3 = conv_stats(cur, ch, hh, ww, f"{name}.downsample.0", planes, raw2, 2, 1, stride=stv)
                     hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=raw2, res_stats=s3)
                 else:
                     hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=cur)
