@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 13
+#define VFML_ABI_VERSION 14
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -98,7 +98,9 @@ int vfml_conv2d(const vfml_conv_desc* d, void* stream);
  * bits).  d->weight is ignored; w_hi / w_lo are the two f16 planes [cout][kp] made by
  * vfml_split_f16 from the [cout][K] weight matrix times `w_scale`, kp = K rounded up to a multiple
  * of 32; the kernel divides the accumulator by w_scale.  Activations stay fp32 in HBM and are split
- * while staged into LDS. */
+ * while staged into LDS.
+ * w_lo == NULL: the second operand is ONE plain f16 plane (up to 2 GiB), a product is two MFMAs (a_hi b + a_lo b);
+ * GEMM form only (split-row source, 1x1 over whole 32-channel blocks, plain f32 out, cout >= 1024). */
 int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
                       int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream);
 /* in_fmt: format of in0/in1; out_fmt: of out; aux_fmt: of aux0/aux1 (VFML_FMT_*).
@@ -135,6 +137,20 @@ int vfml_split_f16(const float* src, int64_t rows, int k, int ld, float scale, v
  * with 288 GB of HBM the P x P score matrix of one frame simply stays resident). */
 int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out, float scale,
                           void* stream);
+
+/* The same softmax as ONE round-to-nearest f16 per element, rows of ld_out halves (ld_out % 8 == 0, <= 32768): the
+ * hi-only weight plane of vfml_conv2d_split (w_lo == NULL).  For MemFlow's attention matrix this halves the bytes
+ * its 12 read-outs per field stream; 2^-12 relative per probability, unbiased (measured: 1080p EPE unchanged). */
+int vfml_softmax_rows_f16(const float* x, int64_t rows, int cols, int64_t ld_in, void* out, int64_t ld_out, float scale,
+                          void* stream);
+
+/* src f32 [rows][c] (row stride ld) -> SPLIT ROWS of its transpose times scale: dst[c][ld_dst] (VFML_FMT_S16, ld_dst =
+ * rows rounded up to 32, pad channels zero): the activation operand of out^T = V^T . A^T. */
+int vfml_transpose_to_s16(const float* src, int rows, int c, int ld, float scale, float* dst, int64_t ld_dst, void* stream);
+
+/* out = aux + scale * x:  x f32 [rows][ldx], aux / out split rows (c % 8 == 0 channels). */
+int vfml_add_to_s16(const float* x, int64_t ldx, const float* aux, int64_t ld_aux, float* out, int64_t ld_out, int64_t rows,
+                    int c, float scale, void* stream);
 
 /* src f32 [rows][c] (row stride ld) -> split-f16 planes of its TRANSPOSE times scale: hi/lo [c][kp],
  * kp >= rows, kp % 32 == 0, zero padded: the "weight" operand of out = attn . V. */

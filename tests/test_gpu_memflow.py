@@ -105,6 +105,47 @@ def test_softmax_rows_and_transposed_planes(gpu):
     assert ((rec[:, :50] - v.t()).abs() <= 2.0 ** -20 * v.t().abs() + 2.0 ** -22).all()
 
 
+@pytest.mark.parametrize("P", [1100, 2500])
+def test_readout_with_the_attention_as_a_plain_f16_plane(gpu, P):
+    """The shipped read-out: scores -> vfml_softmax_rows_f16 (one f16 per probability, times 2^14) as the weight plane,
+    V^T as split rows, one GEMM  out_t[P][128] = A . V, then m + gamma * out_t into split rows."""
+    from tests_support import s16_decode
+    from vfml import hip
+    g = torch.Generator().manual_seed(P)
+    d, scale, gamma = 128, 16384.0, 0.37
+    kp = (P + 31) // 32 * 32
+    scores = torch.randn(P, kp, generator=g) * 2
+    V = torch.randn(P, d, generator=g)
+    m = torch.randn(P, d, generator=g)
+    A = torch.softmax(scores[:, :P].double(), dim=-1)
+    w = hip.PlainWeight(P, kp, gpu, scale=scale)
+    w.hi.fill_(7.0)
+    hip.softmax_rows_f16(scores.cuda().reshape(-1), P, P, kp, w)
+    plane = w.hi.view(P, kp).float().cpu() / scale
+    assert (plane[:, P:] == 0).all()
+    assert ((plane[:, :P].double() - A).abs() <= 2.0 ** -11 * A + 1e-9).all()          # round to nearest: half an ulp
+    vt = torch.full((d * kp,), 5.0, device=gpu)
+    hip.transpose_to_s16(V.cuda().reshape(-1), P, d, d, vt, kp, scale=16.0)
+    vdec = s16_decode(vt, d, kp, kp) / 16.0
+    assert (vdec[:, P:] == 0).all()
+    assert ((vdec[:, :P] - V.t()).abs() <= 2.0 ** -20 * V.t().abs() + 2.0 ** -22).all()
+    out = torch.empty(d * kp, device=gpu)
+    out_t = torch.empty(P * d, device=gpu)
+    hip.conv2d(vt, kp, kp, d, 1, 1, w, None, P, 1, 1, out, kp, out_scale=1.0 / 16.0, in_fmt=hip.FMT_S16, out_t=out_t, ld_out_t=d)
+    ref = plane[:, :P].double() @ V.double()               # with the plane's own rounding: the GEMM itself is fp32-grade
+    got_t = out_t.view(P, d).cpu().double()
+    assert (got_t - ref).abs().max().item() < 2e-6 * ref.abs().max().item() + 1e-6
+    assert (out.view(d, kp)[:, :P].cpu().double() - ref.t()).abs().max().item() < 2e-6 * ref.abs().max().item() + 1e-6
+    # against the exact read-out: at most half an f16 ulp per probability, |sum p eps v| <= 2^-12 sum p |v|
+    assert ((got_t - A @ V.double()).abs() <= 2.0 ** -11 * (A @ V.double().abs()) + 1e-6).all()
+    m16 = torch.empty(P * d, device=gpu)
+    hip.to_s16(m.cuda().reshape(-1), P, d, d, m16, d)
+    res = torch.empty(P * d, device=gpu)
+    hip.add_to_s16(out_t, d, m16, d, res, d, P, d, scale=gamma)
+    want = m.double() + gamma * got_t
+    assert (s16_decode(res, P, d, d).double() - want).abs().max().item() < 5e-6        # split rows: 22 bits of |m| <= 5
+
+
 def test_add_aux_epilogue_is_attention_readout(gpu):
     """out = m + gamma * (A @ V) with A in split rows and V as transposed planes: the per-iteration GEMM."""
     from tests_support import s16_decode

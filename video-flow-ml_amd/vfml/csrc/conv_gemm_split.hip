@@ -78,6 +78,7 @@ struct SplitArgs {
   int tilebase;   // 1x1 over one source: the source descriptor starts at the tile's first row (sources > 2 GiB)
   float* out_t; int ld_out_t;   // GEMM form: transposed second output (or null)
   int cswap;                    // VFML_CONV_SWAP_CROSS
+  int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
   double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
 };
 
@@ -557,7 +558,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 // FASTK: the uniform-step loader (SplitArgs::fastk) as a compile-time choice - with both loaders in one
 // body hipcc stops unrolling the MFMA loops of the larger tiles and the accumulators go to scratch.
 // CSWAP: VFML_CONV_SWAP_CROSS as a compile-time choice (GEMM form only; a runtime branch in the MFMA loop spills).
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false>
+// BHI: the weight operand is one plain f16 plane (hi only, SplitArgs::bhi): its lo slots are never fetched (those
+// lanes of a weight piece carry an out-of-range offset) nor read, and a product is two MFMAs (a_hi b + a_lo b).
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, bool BHI = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int col = n0 + 8 * NW * j + lrow;
-      colbase[j] = col < a.cout ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : 0x40000000;
+      colbase[j] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : (BHI ? 0x7ffffff0 : 0x40000000);
     }
     if (a.tilebase) {
       // GEMM rows of a source that can exceed what one descriptor spans: base it at this tile's first row
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const h16x8*>(base + (boff ^ (ks * 64)) + j * 4096);
-        bl[j] = *reinterpret_cast<const h16x8*>(base + (boff ^ (ks * 64 + 16)) + j * 4096);
+        if constexpr (!BHI) bl[j] = *reinterpret_cast<const h16x8*>(base + (boff ^ (ks * 64 + 16)) + j * 4096);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           } else {
 #ifndef VFML_EXPERIMENT_2MFMA     // timing / accuracy experiment: second operand (weights) as plain f16
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            if constexpr (!BHI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
           }
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false>
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, bool BHI = false>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
   constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
@@ -1001,7 +1004,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   a.ntiles = (a.cout + TBN - 1) / TBN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, BHI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1013,7 +1016,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.mtiles * a.ntiles;
   const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
   const int grid = (int)(PERSIST && total > slots ? slots : total);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, BHI>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
@@ -1021,6 +1024,7 @@ template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
   if (a.direct) {   // (128 x 128: the one persistent tile shape that does not spill)
     if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk)
+    if (a.bhi) return launch_dma_k<2, 2, 2, 2, true, true, false, true>(a, s);  // (host: bhi implies fastk, no cswap)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
   }
   if constexpr (WM * WN == 4 && TM * TN >= 2) {   // the shapes the dispatcher picks by itself
@@ -1144,7 +1148,9 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_kernel(const float* __re
 // The same for rows of at most 256 * 4 * SOFTMAX_REG_QUADS columns: the row is read once (16-byte loads, all in
 // flight together) and stays in registers for the max, the sum of exp and the write - one exp per element instead
 // of two, no second and third sweep through L2.
+// PLAIN16: the result leaves as one round-to-nearest f16 per element (rows of ld_out halves) instead of split rows.
 constexpr int SOFTMAX_REG_QUADS = 32;
+template <bool PLAIN16>
 __global__ __launch_bounds__(256) void softmax_rows_s16_reg_kernel(const float* __restrict__ x, int cols, int64_t ld_in,
                                                                    float* __restrict__ out, int64_t ld_out, float scale) {
   __shared__ float red[4];
@@ -1188,7 +1194,14 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_reg_kernel(const float* 
 #pragma unroll
   for (int i = 0; i < SOFTMAX_REG_QUADS; ++i) {
     const int c = (t + 256 * i) * 4;
-    if (c < ld_out) {
+    if constexpr (PLAIN16) {
+      if (c < ld_out) {
+        const f32x4 pv = v[i] * inv;
+        typedef _Float16 h16x4_ __attribute__((ext_vector_type(4)));
+        const h16x4_ h = {(_Float16)pv[0], (_Float16)pv[1], (_Float16)pv[2], (_Float16)pv[3]};
+        *reinterpret_cast<h16x4_*>(reinterpret_cast<_Float16*>(out) + (int64_t)blockIdx.x * ld_out + c) = h;
+      }
+    } else if (c < ld_out) {
       U8 hh, ll;
       split4(v[i] * inv, hh, ll, 0);
 #ifdef VFML_EXPERIMENT_ATT_HI_ONLY   // precision experiment: probabilities as one round-to-nearest f16
@@ -1201,6 +1214,56 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_reg_kernel(const float* 
       *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hh.v, hh.v, 0, 1, 2, 3));
       *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(ll.v, ll.v, 0, 1, 2, 3));
     }
+  }
+}
+
+// [rows][c] f32 -> split ROWS of the transpose times scale: dst row = source column, its channels = source rows
+// (64 x 64 tiles through LDS, both sides coalesced): the activation operand of  out^T = V^T . A^T
+__global__ __launch_bounds__(256) void transpose_to_s16_kernel(const float* __restrict__ src, int rows, int c, int ld,
+                                                               float scale, _Float16* __restrict__ dst, int64_t ld_dst_h) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int rr = i >> 6, cc = i & 63;
+    const int r = r0 + rr, col = c0 + cc;
+    tile[rr][cc] = (r < rows && col < c) ? src[(int64_t)r * ld + col] * scale : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+    const int cc = i >> 5, kk = (i & 31) * 2;
+    const int col = c0 + cc, k = r0 + kk;
+    if (col >= c || 2 * (int64_t)k >= ld_dst_h) continue;       // (rows past `rows` inside the row stride: zeros)
+    const float a = tile[kk][cc], b = tile[kk + 1][cc];
+    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    _Float16* u = dst + (int64_t)col * ld_dst_h + (k >> 3) * 16 + (k & 7);   // unit k/8: 8 hi halves, then 8 lo halves
+    *reinterpret_cast<fp16x2*>(u) = h;
+    *reinterpret_cast<fp16x2*>(u + 8) = l;
+  }
+}
+
+// out (split rows) = aux (split rows) + scale * x (f32), c channels per row
+__global__ void add_to_s16_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ aux, int64_t ld_aux,
+                                  float* __restrict__ out, int64_t ld_out, int64_t rows, int c, float scale) {
+  const int q4 = c / 4;
+  const int64_t total = rows * q4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / q4;
+    const int col = (int)(i - row * q4) * 4;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + col);
+    const char* ua = reinterpret_cast<const char*>(aux + row * ld_aux + (col & ~7)) + (col & 4) * 2;
+    const h16x2 h0 = *reinterpret_cast<const h16x2*>(ua), h1 = *reinterpret_cast<const h16x2*>(ua + 4);
+    const h16x2 l0 = *reinterpret_cast<const h16x2*>(ua + 16), l1 = *reinterpret_cast<const h16x2*>(ua + 20);
+    f32x4 v;
+    v[0] = ((float)h0[0] + (float)l0[0]) + scale * xv[0];
+    v[1] = ((float)h0[1] + (float)l0[1]) + scale * xv[1];
+    v[2] = ((float)h1[0] + (float)l1[0]) + scale * xv[2];
+    v[3] = ((float)h1[1] + (float)l1[1]) + scale * xv[3];
+    U8 hi, lo;
+    split4(v, hi, lo, 0);
+    char* u = reinterpret_cast<char*>(out + row * ld_out + (col & ~7)) + (col & 4) * 2;
+    *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+    *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
   }
 }
 
@@ -1224,12 +1287,49 @@ extern "C" int vfml_softmax_rows_s16(const float* x, int64_t rows, int cols, int
   VFML_REQUIRE((reinterpret_cast<uintptr_t>(out) & 31u) == 0, "vfml_softmax_rows_s16: out must be 32-byte aligned");
   static const int sweep = getenv("VFML_SOFTMAX_SWEEPS") ? atoi(getenv("VFML_SOFTMAX_SWEEPS")) : 0;
   if (ld_out <= 256 * 4 * SOFTMAX_REG_QUADS && !sweep)
-    hipLaunchKernelGGL(softmax_rows_s16_reg_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(softmax_rows_s16_reg_kernel<false>, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        x, cols, ld_in, out, ld_out, scale);
   else
     hipLaunchKernelGGL(softmax_rows_s16_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                        cols, ld_in, out, ld_out, scale);
   return vfml_check_launch("vfml_softmax_rows_s16");
+}
+
+extern "C" int vfml_softmax_rows_f16(const float* x, int64_t rows, int cols, int64_t ld_in, void* out, int64_t ld_out,
+                                     float scale, void* stream) {
+  VFML_REQUIRE(x && out && rows > 0 && rows < (1ll << 31) && cols > 0 && ld_in >= cols && ld_out >= cols && ld_out % 8 == 0,
+               "vfml_softmax_rows_f16: bad shape (ld_out %% 8 == 0, ld_out >= cols)");
+  VFML_REQUIRE(ld_out <= 256 * 4 * SOFTMAX_REG_QUADS, "vfml_softmax_rows_f16: rows of at most %d columns", 256 * 4 * SOFTMAX_REG_QUADS);
+  VFML_REQUIRE(vfml_aligned16(out), "vfml_softmax_rows_f16: out must be 16-byte aligned");
+  VFML_REQUIRE(scale >= 1.0f && scale <= 32768.0f, "vfml_softmax_rows_f16: scale %g out of [1, 2^15]", (double)scale);
+  hipLaunchKernelGGL(softmax_rows_s16_reg_kernel<true>, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     x, cols, ld_in, (float*)out, ld_out, scale);
+  return vfml_check_launch("vfml_softmax_rows_f16");
+}
+
+extern "C" int vfml_transpose_to_s16(const float* src, int rows, int c, int ld, float scale, float* dst, int64_t ld_dst,
+                                     void* stream) {
+  VFML_REQUIRE(src && dst && rows > 0 && c > 0 && ld >= c && scale > 0.f, "vfml_transpose_to_s16: bad argument");
+  VFML_REQUIRE(ld_dst % 32 == 0 && ld_dst >= rows && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0,
+               "vfml_transpose_to_s16: ld_dst must be rows rounded up to 32, dst 32-byte aligned");
+  // every 64-row block that touches the row stride is swept, so the pad channels are written (zeros)
+  hipLaunchKernelGGL(transpose_to_s16_kernel, dim3((unsigned)((ld_dst + 63) / 64), (c + 63) / 64), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, rows, c, ld, scale, (_Float16*)dst, 2 * ld_dst);
+  return vfml_check_launch("vfml_transpose_to_s16");
+}
+
+extern "C" int vfml_add_to_s16(const float* x, int64_t ldx, const float* aux, int64_t ld_aux, float* out, int64_t ld_out,
+                               int64_t rows, int c, float scale, void* stream) {
+  VFML_REQUIRE(x && aux && out && rows > 0 && c > 0 && c % 8 == 0, "vfml_add_to_s16: bad argument (c %% 8 == 0)");
+  VFML_REQUIRE(ldx % 4 == 0 && ldx >= c && ld_aux % 8 == 0 && ld_out % 8 == 0 && vfml_aligned16(x) &&
+               (reinterpret_cast<uintptr_t>(aux) & 31u) == 0 && (reinterpret_cast<uintptr_t>(out) & 31u) == 0,
+               "vfml_add_to_s16: alignment (x 16 bytes / ldx %% 4, split rows 32 bytes / ld %% 8)");
+  const int64_t total = rows * (c / 4);
+  int64_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(add_to_s16_kernel, dim3((unsigned)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, aux,
+                     ld_aux, out, ld_out, rows, c, scale);
+  return vfml_check_launch("vfml_add_to_s16");
 }
 
 extern "C" int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream) {
@@ -1287,7 +1387,9 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                  (!d->aux1 || (d->ld_aux1 % 8 == 0 && (reinterpret_cast<uintptr_t>(d->aux1) & 31u) == 0)) &&
                  (d->epilogue != VFML_EPI_GRU_ZR || d->split % 8 == 0),
                  "vfml_conv2d_split: split-row aux operands need 32-byte aligned bases, ld %% 8 == 0, cout %% 4 == 0");
-  VFML_REQUIRE(d->in0 && w_hi && w_lo && d->out, "vfml_conv2d_split: null in0/w_hi/w_lo/out");
+  VFML_REQUIRE(d->in0 && w_hi && d->out, "vfml_conv2d_split: null in0/w_hi/out");
+  const bool bhi = w_lo == nullptr;    // one plain f16 weight plane (GEMM form only, checked below)
+  VFML_REQUIRE(!bhi || in_fmt == VFML_FMT_S16, "vfml_conv2d_split: a weight operand without lo plane needs split-row sources");
   VFML_REQUIRE(d->c0 > 0 && d->c0 % 4 == 0 && d->ld0 % 4 == 0 && d->ld0 >= d->c0,
                "vfml_conv2d_split: c0=%d ld0=%d must be multiples of 4 with ld0>=c0", d->c0, d->ld0);
   const bool two = d->in1 != nullptr;
@@ -1297,7 +1399,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(d->kh > 0 && d->kw > 0 && d->kh * d->kw < 64 && d->stride > 0 && d->pad_h >= 0 && d->pad_w >= 0,
                "vfml_conv2d_split: bad kernel geometry (kh*kw must be < 64)");
   VFML_REQUIRE(d->ldo >= d->cout, "vfml_conv2d_split: ldo=%d < cout=%d", d->ldo, d->cout);
-  VFML_REQUIRE(vfml_aligned16(d->in0) && vfml_aligned16(w_hi) && vfml_aligned16(w_lo) && (!two || vfml_aligned16(d->in1)),
+  VFML_REQUIRE(vfml_aligned16(d->in0) && vfml_aligned16(w_hi) && (bhi || vfml_aligned16(w_lo)) && (!two || vfml_aligned16(d->in1)),
                "vfml_conv2d_split: in0/in1/w_hi/w_lo must be 16-byte aligned");
   VFML_REQUIRE(w_scale > 0.f, "vfml_conv2d_split: w_scale must be the positive scale given to vfml_split_f16");
   const int K = d->kh * d->kw * (d->c0 + d->c1);
@@ -1321,7 +1423,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                  "vfml_conv2d_split: a source spans >= 1 GiB");
   }
   {
-    VFML_REQUIRE(((int64_t)d->cout + 128) * kp * 2 < (1ll << 30), "vfml_conv2d_split: weight planes too large");
+    VFML_REQUIRE(bhi ? (int64_t)d->cout * kp * 2 <= 0x7ffffff0ll : ((int64_t)d->cout + 128) * kp * 2 < (1ll << 30),
+                 "vfml_conv2d_split: weight planes too large");
   }
   if (d->epilogue == VFML_EPI_GRU_ZR || d->epilogue == VFML_EPI_TANH_RELU)
     VFML_REQUIRE(d->split > 0 && d->split < d->cout && d->split % 4 == 0,
@@ -1332,7 +1435,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(d->epilogue >= VFML_EPI_NONE && d->epilogue <= VFML_EPI_ADD_AUX, "vfml_conv2d_split: bad epilogue");
 
   SplitArgs a;
-  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0;
+  a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0; a.bhi = 0;
   a.stats_part = d->stats_part;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
@@ -1384,12 +1487,14 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   if (in16) {   // split-row sources: every slice is a multiple of 8 channels and >= one K step wide
     // LDS-DMA kernel when both weight planes fit one descriptor window (< 1 GiB)
     const char* ph = (const char*)w_hi;
-    const char* pl = (const char*)w_lo;
+    const char* pl = bhi ? ph : (const char*)w_lo;
     const char* wb = ph < pl ? ph : pl;
     const int64_t ext = (ph < pl ? pl - ph : ph - pl) + (int64_t)d->cout * kp * 2;
-    const bool dma_ok = ext < (1ll << 30);
+    // (a single plane may span up to 2 GiB: its lanes' out-of-range marker is 0x7ffffff0 instead of 1 GiB)
+    const bool dma_ok = bhi ? ext <= 0x7ffffff0ll : ext < (1ll << 30);
     if (dma_ok) {   // every split-row source goes through the LDS-DMA kernel
       a.wbase = wb; a.whi_off = (int)(ph - wb); a.wlo_off = (int)(pl - wb); a.bytesb = (int)ext;
+      a.bhi = bhi ? 1 : 0;
       a.tilebase = tilebase;
       {
         static const int no_fastk = getenv("VFML_NO_FASTK") ? atoi(getenv("VFML_NO_FASTK")) : 0;
@@ -1412,6 +1517,9 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                                           "(1x1 over whole 32-channel blocks, plain f32 out, cout >= 1024, cout %% 4 == 0)");
         a.cswap = 1;
       }
+      if (bhi)
+        VFML_REQUIRE(a.direct && a.fastk && !a.cswap, "vfml_conv2d_split: a weight operand without lo plane is implemented by the "
+                                                        "GEMM form only (1x1 over whole 32-channel blocks, plain f32 out, cout >= 1024)");
       if (d->out_t) {
         VFML_REQUIRE(a.direct && a.fastk && a.pointwise && !d->bias && d->epilogue == VFML_EPI_NONE && a.M % 4 == 0 &&
                      d->ld_out_t % 4 == 0 && d->ld_out_t >= a.M && vfml_aligned16(d->out_t),

@@ -83,6 +83,9 @@ def lib():
     L.vfml_instnorm_workspace_bytes.restype = c_int64
     L.vfml_instnorm_workspace_bytes.argtypes = [c_int, c_int, c_int]
     L.vfml_instnorm_stats.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]
+    L.vfml_softmax_rows_f16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_float, c_void_p]
+    L.vfml_transpose_to_s16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]
+    L.vfml_add_to_s16.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]
     L.vfml_instnorm_finalize.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
@@ -100,14 +103,14 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 13:
+    if L.vfml_abi_version() != 14:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
 
 
 EXPORTS = [
-    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16",
+    "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
     "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
@@ -183,7 +186,7 @@ def profile_end():
 
 
 def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False,
-                 cswap=False):
+                 cswap=False, bhi=False):
     """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
     the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
     split kernel for cout > 64 is not modelled)."""
@@ -194,11 +197,12 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
     if dma:     # split-f16, LDS-DMA staged
         fk = "true" if fastk else "false"       # uniform-step loader (SplitArgs::fastk)
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
-            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}>"   # persistent GEMM form
+            return (f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, "
+                    f"{'true' if bhi else 'false'}>")   # persistent GEMM form
         if cout <= 32:
-            return "conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false>"
+            return "conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, false>"
         if cout <= 64:
-            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false>"
+            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, false>"
         def cost(tbm, tbn, mf, eff):
             tiles = -(-m // tbm) * -(-cout // tbn)
             return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
@@ -209,7 +213,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         for c, name in cands[1:]:
             if c < best:
                 best, t = c, name
-        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false>"
+        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, false>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
 
@@ -262,7 +266,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
     d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
     d.n, d.h, d.w = n, h, w
-    is_split = isinstance(weight, SplitWeight)
+    is_split = isinstance(weight, (SplitWeight, PlainWeight))
     d.weight = None if is_split else _ptr(_dev(weight), weight_off)
     d.bias = _ptr(_dev(bias)) if bias is not None else None
     d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w = cout, kh, kw, stride, pad_h, pad_w
@@ -278,7 +282,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         # weight_off counts rows of the split planes (each row kp halves)
         def launch():
             _check(lib().vfml_conv2d_split(ctypes.byref(d), c_void_p(weight.hi.data_ptr() + 2 * weight_off * weight.kp),
-                                           c_void_p(weight.lo.data_ptr() + 2 * weight_off * weight.kp), weight.kp,
+                                           c_void_p(weight.lo.data_ptr() + 2 * weight_off * weight.kp) if weight.lo is not None else None, weight.kp,
                                            weight.scale, in_fmt, out_fmt, aux_fmt, weight.order, _stream()),
                    "vfml_conv2d_split")
     else:
@@ -303,7 +307,8 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
              and c0 % 32 == 0 and ctot % 32 == 0 and kh * kw <= 32 and not os.environ.get("VFML_NO_FASTK")
              and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
-                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross),
+                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
+                                  is_split and weight.lo is None),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
 
 
@@ -349,6 +354,36 @@ def softmax_rows_s16(x, rows, cols, ld_in, out, ld_out, x_off=0, out_off=0, scal
     """scale * row softmax of f32 scores -> split rows (FMT_S16), zero-filled to ld_out."""
     _check(lib().vfml_softmax_rows_s16(_ptr(_dev(x), x_off), rows, cols, ld_in, _ptr(_dev(out), out_off), ld_out,
                                        float(scale), _stream()), "vfml_softmax_rows_s16")
+
+
+class PlainWeight:
+    """One f16 plane [rows][kp] as the second operand of a GEMM (vfml_conv2d_split with w_lo == NULL)."""
+    lo = None
+    order = KORDER_TAP
+
+    def __init__(self, rows, kp, device, scale=1.0):
+        if kp % 32:
+            raise ValueError("PlainWeight: kp must be a multiple of 32")
+        self.rows, self.k, self.kp, self.scale = rows, kp, kp, float(scale)
+        self.hi = torch.empty(rows * kp, dtype=torch.float16, device=device)
+
+
+def softmax_rows_f16(x, rows, cols, ld_in, weight, x_off=0):
+    """weight.scale * row softmax of f32 scores -> the f16 plane of a PlainWeight (rows of weight.kp halves)."""
+    _check(lib().vfml_softmax_rows_f16(_ptr(_dev(x), x_off), rows, cols, ld_in, c_void_p(weight.hi.data_ptr()), weight.kp,
+                                       weight.scale, _stream()), "vfml_softmax_rows_f16")
+
+
+def transpose_to_s16(src, rows, c, ld, dst, ld_dst, scale=1.0, src_off=0, dst_off=0):
+    """f32 [rows][c] -> split rows [c][ld_dst] of its transpose times scale."""
+    _check(lib().vfml_transpose_to_s16(_ptr(_dev(src), src_off), rows, c, ld, float(scale), _ptr(_dev(dst), dst_off), ld_dst,
+                                       _stream()), "vfml_transpose_to_s16")
+
+
+def add_to_s16(x, ldx, aux, ld_aux, out, ld_out, rows, c, scale=1.0, x_off=0, aux_off=0, out_off=0):
+    """out = aux + scale * x (x f32, aux / out split rows)."""
+    _check(lib().vfml_add_to_s16(_ptr(_dev(x), x_off), ldx, _ptr(_dev(aux), aux_off), ld_aux, _ptr(_dev(out), out_off), ld_out,
+                                 rows, c, float(scale), _stream()), "vfml_add_to_s16")
 
 
 def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):

@@ -24,6 +24,7 @@ from .weights import pack_conv_weight
 # attention probabilities are stored times 2^14 (split rows hold f16 halves: an unscaled 1080p row, 32400 probabilities
 # of 3e-5 on average, would sit in the f16 subnormals); the read-out GEMM divides it out through out_scale
 ATT_SCALE = float(os.environ.get("VFML_ATT_SCALE", "16384"))      # (override: precision experiments)
+ATT_PLAIN = os.environ.get("VFML_ATT_SPLIT_ROWS", "0") != "1"       # 1: keep the probabilities as split rows (hi + lo)
 
 
 def memflow_conv_spec(cfg):
@@ -81,7 +82,12 @@ class MemFlowNetHIP(MOFNetHIP):
         self._packed_key = None
         self._packed_serial = 0
         self._ws = {}
+        self._att_planes = {}            # attention matrices as plain f16 planes (hip.PlainWeight), per pair of a pass
         self._feat_cache = collections.OrderedDict()
+
+    def release_workspace(self):
+        super().release_workspace()
+        self._att_planes.clear()
 
     # ------------------------------------------------------------------ weights
     def _pack(self, device):
@@ -224,13 +230,23 @@ class MemFlowNetHIP(MOFNetHIP):
             wgt, b = P["key"]
             hip.conv2d(G, 128, GLD, B, h, w, wgt, b, AD, 1, 1, kmap, AD, in0_off=INP, in_fmt=AF)
             scores = self._buf("att_scores", Pn * ldA, dev)
+            # probabilities as ONE f16 each (round to nearest, times ATT_SCALE): the read-out streams the matrix 12 times
+            # per field and is bound by its bytes; 2^-12 relative per probability, unbiased - the 1080p EPE does not move
+            # (tests/test_gpu_memflow.py).  The matrix is then the WEIGHT plane of the read-out GEMM (out^T = V^T . A^T).
+            plain = ATT_PLAIN and Pn >= 1024 and Pn % 4 == 0 and Pn * ldA * 2 <= 0x7ffffff0 and ldA <= 32768
             attn = []
             for k in range(B):
                 kw_ = hip.SplitWeight(Pn, AD, dev).fill(kmap, src_off=k * Pn * AD, scale=16.0)
                 hip.conv2d(qmap, AD, AD, 1, 1, Pn, kw_, None, Pn, 1, 1, scores, ldA, in0_off=k * Pn * AD,
                            out_scale=1.0 / float(AD) ** 0.5, in_fmt=AF)
-                a = self._buf(f"att_probs{k}", Pn * ldA, dev)
-                hip.softmax_rows_s16(scores, Pn, Pn, ldA, a, ldA, scale=ATT_SCALE)
+                if plain:
+                    a = self._att_planes.get(k)
+                    if a is None or a.rows != Pn or a.kp != ldA or a.hi.device != dev:
+                        a = self._att_planes[k] = hip.PlainWeight(Pn, ldA, dev, scale=ATT_SCALE)
+                    hip.softmax_rows_f16(scores, Pn, Pn, ldA, a)
+                else:
+                    a = self._buf(f"att_probs{k}", Pn * ldA, dev)
+                    hip.softmax_rows_s16(scores, Pn, Pn, ldA, a, ldA, scale=ATT_SCALE)
                 attn.append(a)
 
             corr = self._buf("mcorr", MP * cor_p, dev, zero=True)
@@ -242,7 +258,12 @@ class MemFlowNetHIP(MOFNetHIP):
             flow4 = self._buf("flow4", MP * 4, dev)
             delta = self._buf("mdelta", MP * 4, dev, zero=True)     # channels 2,3 stay zero: no backward flow here
             coords1 = self._buf("coords1", MP * 4, dev)
-            vt = hip.SplitWeight(AD, P8, dev)
+            if plain:
+                vrows = self._buf("att_vt", AD * ldA, dev)            # V^T as split rows [AD][ldA]
+                ro = self._buf("att_ro", AD * ldA, dev)               # the GEMM's primary output [AD][ldA] (unused)
+                ro_t = self._buf("att_ro_t", Pn * AD, dev)            # its transpose: attn . v, [Pn][AD]
+            else:
+                vt = hip.SplitWeight(AD, P8, dev)
 
             hip.coords_init(coords1, B, h, w)
             hip.coords_update(coords1, None, B, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
@@ -268,7 +289,13 @@ class MemFlowNetHIP(MOFNetHIP):
                 # value map and memory read-out  m_global = m + gamma * attn . v  (per pair: its own attention)
                 wgt, b = P[f"{ub}.value"]
                 hip.conv2d(G, 128, GLD, B, h, w, wgt, b, AD, 1, 1, val, AD, in0_off=MF, in_fmt=AF)
-                for k in range(B):
+                for k in range(B if plain else 0):
+                    hip.transpose_to_s16(val, Pn, AD, AD, vrows, ldA, scale=16.0, src_off=k * Pn * AD)
+                    hip.conv2d(vrows, ldA, ldA, AD, 1, 1, attn[k], None, Pn, 1, 1, ro, ldA, out_scale=1.0 / 16.0,
+                               in_fmt=AF, out_t=ro_t, ld_out_t=AD)
+                    hip.add_to_s16(ro_t, AD, G, GLD, G, GLD, Pn, AD, scale=gamma, aux_off=k * Pn * GLD + MF,
+                                   out_off=k * Pn * GLD + MT)
+                for k in range(0 if plain else B):
                     vt.fill_transposed(val, Pn, ld=AD, scale=16.0, src_off=k * Pn * AD)
                     # rows as the batch axis (1x1 "images"): one GEMM over the whole 4.2 GB attention matrix -
                     # the LDS-DMA kernel bases its source descriptor at each tile's first row
