@@ -208,14 +208,16 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         split = "split" in name or "dma" in name      # both are split-f16 kernels (3 f16 MFMAs per product)
         peak = F16_MATRIX_PEAK_TFLOPS / 3.0 if split else F32_MATRIX_PEAK_TFLOPS
+        traffic, traffic_note = hbm_traffic_from_profiles(name, args.workload)
         result["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
             "peak_note": ("algorithmic FLOP/s; peak = 2500 TFLOP/s dense f16 MFMA / 3 MFMAs per product"
                           if split else "f32 matrix peak (v_mfma_f32_32x32x2_f32)"),
             "mfma_executed_tflops": achieved * (3.0 if split else 1.0),
             "launches": d["launches"], "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
             "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "share_of_step": d["ms"] / (1000.0 * t_compute),
             "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                  "launches": v["launches"]} for k, v in prof.items()},
@@ -230,6 +232,25 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, proc, clip_np, fields[Wm], out[0], T)
     print(json.dumps(result))
+
+
+def hbm_traffic_from_profiles(kernel, workload):
+    """HBM bytes per launch of `kernel` from the PMC passes over this very command (a live run cannot collect them:
+    rocprofv3 has to wrap the process).  profiles/r01_j_hbm_traffic.json holds the per-kernel means of the default
+    workload; None for any other workload or when the file / the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic.json")
+    if workload != "mof1080p" or not os.path.exists(path):
+        return None, "no PMC passes recorded for this workload"
+    try:
+        with open(path) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        rec = None
+    if not rec:
+        return None, "kernel not in profiles/r01_j_hbm_traffic.json"
+    return rec["hbm_bytes_per_launch"], ("bytes per launch, mean over %d launches: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate "
+                                         "rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1` (profiles/r01_j_hbm_traffic.json)"
+                                         % rec["launches"])
 
 
 def host_cpu_share(cap=16):

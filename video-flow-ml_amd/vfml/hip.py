@@ -171,16 +171,18 @@ def profile_end_hbm():
 
 
 def profile_end():
-    """Stop recording; returns {variant: {"launches", "flops", "ms"}} (synchronises)."""
+    """Stop recording; returns {variant: {"launches", "flops", "bytes", "ms"}} (synchronises); bytes = every operand
+    read once and the result written once (the algorithmic HBM traffic of the launch)."""
     global _PROFILE, _PROFILE_HBM
     rec, _PROFILE = _PROFILE or [], None
     _PROFILE_HBM = None
     torch.cuda.synchronize()
     out = {}
-    for variant, flops, e0, e1 in rec:
-        d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
+    for variant, flops, nbytes, e0, e1 in rec:
+        d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
         d["launches"] += 1
         d["flops"] += flops
+        d["bytes"] += nbytes
         d["ms"] += e0.elapsed_time(e1)
     return out
 
@@ -309,7 +311,10 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
                                   weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
                                   is_split and weight.lo is None),
-                     2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout, e0, e1))
+                     2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
+                     # operands read once + result written once, 4 bytes per element in either activation format
+                     4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)
+                            + cout * kh * kw * (c0 + c1) * (0.5 if is_split and weight.lo is None else 1.0)), e0, e1))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):
