@@ -40,6 +40,23 @@ def test_memflow_forward_matches_oracle(gpu, precision):
     assert (low.cpu() - low_ref).abs().max().item() < 1e-3
 
 
+def test_memflow_plain_attention_plane_at_a_small_size(gpu, monkeypatch):
+    """256 x 320: 1280 keys, the smallest size class that takes the one-f16-per-probability read-out; both read-out
+    paths against the oracle, and against each other."""
+    from vfml import memflow_net
+    net, ora = _pair()
+    x = torch.rand(1, 2, 3, 256, 320, generator=torch.Generator().manual_seed(11)) * 2 - 1
+    _, ref = ora(x)
+    _, plain = net(x.cuda())
+    plain = plain.clone()
+    assert len(net._att_planes) == 1                      # the plane path ran
+    monkeypatch.setattr(memflow_net, "ATT_PLAIN", False)
+    _, rows = net(x.cuda())
+    for got in (plain, rows):
+        assert (got.cpu() - ref).pow(2).sum(1).sqrt().mean().item() < 2e-5
+    assert (plain - rows).pow(2).sum(1).sqrt().mean().item() < 2e-5
+
+
 def test_memflow_1080p_matches_oracle(gpu):
     """One pair at the size of BASELINE config C4: 32400 keys per attention row - the probabilities average 3e-5,
     which is where their storage scale (memflow_net.ATT_SCALE) matters."""
