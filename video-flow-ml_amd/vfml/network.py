@@ -478,6 +478,9 @@ class MOFNetHIP(_Holder):
                             for l in range(1, L):
                                 hip.conv2d(feats[tgt][0], D, D, 1, 1, Pn, feats[c][1][l], None, Sl[l], 1, 1, rev[l],
                                            ldl[l], out_scale=scale, in_fmt=AF)
+                        if os.environ.get("VFML_EXPERIMENT_CORR16"):   # precision experiment: the volume rounded to f16
+                            for t in pyr + (rev or []):
+                                t.copy_(t.half().float())
                     pyrs[d].append(pyr)
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
