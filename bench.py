@@ -12,8 +12,10 @@ runs K steps on its own frame range (weak scaling, no data-path collective) and 
 brings the finished fields to rank 0 inside the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      dominant kernel (the f32-MFMA implicit-GEMM conv/GEMM), achieved TFLOP/s from HIP
-                events recorded around its launches inside the timed region, vs the f32 matrix peak
+  roofline      dominant kernel (the split-f16 LDS-DMA implicit-GEMM conv), achieved algorithmic TFLOP/s from HIP
+                events recorded around its launches inside the timed region vs 2500 / 3 TFLOP/s (three f16 MFMAs
+                per product); `traffic`: HBM-side bytes per launch from the PMC passes recorded in
+                profiles/r01_j_hbm_traffic.json beside `algorithmic_bytes_per_launch`; `hbm_kernels`: the lookup
   cpu_baseline  the CPU oracle (oracle/mof_oracle.py, "port") timed on this box's host cores on a
                 bounded sample of the same workload (N=1 only), plus the engine-vs-oracle EPE on it
 """
