@@ -1,5 +1,6 @@
-"""The N>1 path on CPU: two gloo ranks shard (frame, tile) work items, compute with a stand-in model
-through the real processor plumbing, gather to rank 0 — and must reproduce the serial loop exactly."""
+"""The N>1 path on CPU: two or three gloo ranks shard (frame, tile) work items (uneven shards included), compute
+with a stand-in model through the real processor plumbing, stream their finished fields to rank 0 in chunked
+gathers — and must reproduce the serial loop exactly, in the returned array and through `on_field`."""
 import contextlib
 import io
 import os
@@ -35,7 +36,7 @@ def _proc(tile_mode):
     return p
 
 
-def _worker(rank, world, port, tile_mode, q):
+def _worker(rank, world, port, tile_mode, q, chunk=None, fed=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "video-flow-ml_amd"), root):
@@ -47,14 +48,32 @@ def _worker(rank, world, port, tile_mode, q):
     from vfml.runner import run_sharded
     r, _, w = vdist.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
+    from vfml.runner import ClipFeeder
     proc = _proc(tile_mode)
-    clip = proc.upload_clip(_clip())
-    out = run_sharded(proc, clip, range(clip.shape[0]), tile_mode=tile_mode, rank=rank, world=world)
+    seen = {}
+
+    def on_field(k, field, lods):
+        assert k not in seen and lods is None
+        seen[k] = field.copy()
+
+    if fed:         # frames uploaded as the job advances; fields only through the callback
+        feeder = ClipFeeder(_clip(), "cpu")
+        out = run_sharded(proc, None, range(7), tile_mode=tile_mode, rank=rank, world=world, chunk=chunk,
+                          feeder=feeder, on_field=on_field if rank == 0 else None, collect=False)
+        assert out is None
+        if rank == 0:
+            out = np.stack([seen[k] for k in range(7)])
+    else:
+        clip = proc.upload_clip(_clip())
+        out = run_sharded(proc, clip, range(clip.shape[0]), tile_mode=tile_mode, rank=rank, world=world, chunk=chunk,
+                          on_field=on_field if rank == 0 else None)
+        if rank == 0:
+            assert sorted(seen) == list(range(7)) and all(np.array_equal(seen[k], out[k]) for k in seen)
     t = vdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
     vdist.barrier()
     if rank == 0:
         q.put((out, t))
-    else:
+    elif not fed:
         assert out is None
     dist.destroy_process_group()
 
@@ -67,20 +86,22 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("tile_mode", [False, True])
-def test_two_rank_gloo_job_equals_serial_loop(tile_mode):
-    world = 2
+@pytest.mark.parametrize("world,tile_mode,chunk,fed", [(2, False, None, False), (2, True, None, False),
+                                                       (3, False, 1, True), (3, True, 3, False), (3, True, 2, True)])
+def test_gloo_job_equals_serial_loop(world, tile_mode, chunk, fed):
+    """7 frames (x 6 ragged tiles) over 2 or 3 ranks: shards of 4+3, 3+2+2, 14+14+14 items; chunk sizes that do and
+    do not divide a shard (the last gather of a rank then carries unused slots)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tile_mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tile_mode, q, chunk, fed)) for r in range(world)]
     for p in procs:
         p.start()
     out, tmax = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert tmax == 2.0                                           # MAX over ranks
+    assert tmax == float(world)                                  # MAX over ranks
     serial = _proc(tile_mode)
     frames = _clip()
     for i in range(len(frames)):
@@ -104,7 +125,9 @@ def test_single_rank_runner_without_process_group():
     from vfml.runner import run_sharded
     proc = _proc(True)
     clip = proc.upload_clip(_clip(5))
-    out = run_sharded(proc, clip, [1, 3], tile_mode=True)
+    got = []
+    out = run_sharded(proc, clip, [1, 3], tile_mode=True, on_field=lambda k, f, lods: got.append((k, f.copy())))
     ser = _proc(True)
     assert np.array_equal(out[0], ser.compute_optical_flow_tiled(_clip(5), 1))
     assert np.array_equal(out[1], ser.compute_optical_flow_tiled(_clip(5), 3))
+    assert [k for k, _ in got] == [0, 1] and np.array_equal(got[1][1], out[1])

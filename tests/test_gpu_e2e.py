@@ -287,3 +287,57 @@ def test_bof_fields_batched_equal_fields_one_by_one(gpu):
     job = run_sharded(proc, clip, range(12))
     assert np.array_equal(job[5], batched[5].cpu().numpy()) and np.array_equal(job[0], batched[0].cpu().numpy())
     assert np.array_equal(job[7], proc.compute_optical_flow(frames, 7))
+
+
+def test_two_clips_of_one_shape_through_one_engine(gpu):
+    """A clip's frames are cached under the identity of the UPLOAD, not of its device address: clip A is freed
+    before clip B (same shape, different pixels) is uploaded - torch's caching allocator hands B the address A had
+    and a fresh tensor starts at version 0 again - and B's fields still equal a from-scratch forward of B
+    (with (data_ptr, _version) keys they were A's encoder maps and pyramids).  MOF and MemFlow processors."""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.memflow_processor import MemFlowProcessor
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.memflow_net import build_memflow_network, memflow_cfg, seeded_memflow_state_dict
+    from vfml.synth import synthetic_clip
+    net, _ = _pair()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=5)
+    proc.core.model = net
+    fa = synthetic_clip(7, 128, 160)
+    fb = [np.ascontiguousarray(255 - f[::-1]) for f in synthetic_clip(7, 128, 160)]     # same shape, other pixels
+    clip = proc.upload_clip(fa)
+    addr = clip.data_ptr()
+    got_a = [proc.compute_optical_flow_resident(clip, i).clone() for i in (2, 3, 4)]
+    del clip
+    clip = proc.upload_clip(fb)
+    same_addr = clip.data_ptr() == addr
+    got_b = [proc.compute_optical_flow_resident(clip, i).clone() for i in (2, 3, 4)]
+    tri = [f.clone() for f in proc.compute_optical_flow_resident_batch(clip, [3])]
+    net.clear_feature_cache()
+    for k, i in enumerate((2, 3, 4)):
+        ref, _ = net.forward_u8(clip[proc.window_indices(7, i)])
+        ref = ref[0, 3].permute(1, 2, 0)
+        assert torch.equal(got_b[k], ref), (i, same_addr)
+        assert not torch.equal(got_a[k], ref)
+    assert torch.equal(tri[0], got_b[1])
+    print(f"second upload reused the first clip's address: {same_addr}")
+
+    cfg = memflow_cfg()
+    mnet = build_memflow_network(cfg)
+    mnet.load_state_dict(seeded_memflow_state_dict(cfg, 0))
+    mnet.cuda().eval()
+    with contextlib.redirect_stdout(io.StringIO()):
+        mproc = MemFlowProcessor("cuda", sequence_length=3)
+    mproc.core_engine.model = mnet
+    clip = mproc.upload_clip(fa)
+    ma = [f.clone() for f in mproc.compute_optical_flow_resident_batch(clip, [2, 3, 4])]
+    del clip
+    clip = mproc.upload_clip(fb)
+    mb = [f.clone() for f in mproc.compute_optical_flow_resident_batch(clip, [2, 3, 4])]
+    mnet.clear_feature_cache()
+    for k, i in enumerate((2, 3, 4)):
+        ref = mproc.compute_optical_flow_resident(clip, i)
+        assert torch.equal(mb[k], ref), i
+        assert not torch.equal(ma[k], ref)

@@ -267,6 +267,7 @@ def test_cli_fills_cache_with_injected_cpu_model(tmp_path, monkeypatch):
             return None
 
     monkeypatch.setattr(core_mod, "build_network", lambda cfg: Net())
+    monkeypatch.setattr(core_mod, "load_checked", lambda model, state, what: model.load_state_dict(state))
     argv = ["--input", "synthetic:64x48x5", "--output", str(tmp_path / "out"), "--device", "cpu", "--sequence-length",
             "3", "--interactive"]
     with quiet():
@@ -281,6 +282,44 @@ def test_cli_fills_cache_with_injected_cpu_model(tmp_path, monkeypatch):
     with contextlib.redirect_stdout(out):
         assert flow_processor.main(argv) == 0
     assert "nothing to compute" in out.getvalue()
+    # --start-time / --duration select the frame range the reference's way (int(seconds * fps), synthetic clips run
+    # at 30 fps) and name the cache directory after the RESOLVED range (reference flow_processor.py:667-677)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        assert flow_processor.main(argv[:-1] + ["--start-time", "0.07", "--duration", "0.1", "--skip-lods", "--interactive"]) == 0
+    assert "Start time: 0.07s -> frame 2" in out.getvalue() and "Duration: 0.1s -> 3 frames" in out.getvalue()
+    cache2 = tmp_path / "out" / "synthetic_64x48x5_flow_cache_videoflow_mof_sintel_standard_seq3_start2_frames3"
+    assert sorted(os.listdir(cache2)) == [f"flow_frame_{i:06d}.npz" for i in range(3)]
+    # cached frame 0 of that job is frame 2 of the clip, computed on the 3-frame sub-clip
+    from vfml.synth import synthetic_clip
+    sub = synthetic_clip(5, 48, 64)[2:5]
+    with quiet():
+        p = make_proc(sequence_length=3)
+    p.core.model = FakeModel()
+    assert np.array_equal(np.load(cache2 / "flow_frame_000001.npz")["flow"], p.compute_optical_flow(sub, 1))
+    with quiet():
+        assert flow_processor.main(argv[:-1] + ["--start-time", "9", "--interactive"]) == 1    # past the end
+
+
+def test_time_to_frame_and_range_clamp_match_reference():
+    """--start-time / --duration / --start-frame / --frames resolve exactly as the reference's VideoInfo does
+    (fixtures cut from it: tests/golden/make_time_fixtures.py)."""
+    import flow_processor as fp
+    cases = json.load(open(os.path.join(HERE, "golden", "time_ranges.json")))["cases"]
+    assert len(cases) > 200
+    for c in cases:
+        s, n = c["start_frame"], c["frames"]
+        if c["start_time"] is not None:
+            s = fp.time_to_frame(c["start_time"], c["fps"])
+        if c["duration"] is not None:
+            n = fp.time_to_frame(c["duration"], c["fps"])
+        assert [s, n] == c["resolved"], c
+        if "error" in c:
+            with pytest.raises(ValueError) as e:
+                fp.validate_frame_range(s, n, c["total"])
+            assert str(e.value) == c["error"]
+        else:
+            assert list(fp.validate_frame_range(s, n, c["total"])) == c["range"], c
 
 
 def test_memflow_windows_and_errors_match_reference(tmp_path, monkeypatch):

@@ -29,7 +29,7 @@ from processing.flow_inference import VideoFlowInference
 from processing.memflow_inference import MemFlowInference
 from storage import AsyncFlowCacheWriter, FlowCacheManager
 from vfml import dist as vdist
-from vfml.runner import run_sharded
+from vfml.runner import ClipFeeder, run_sharded
 
 
 def build_parser():
@@ -67,7 +67,61 @@ def build_parser():
     return p
 
 
-def load_frames(spec, start_frame, max_frames, fps_default=30.0):
+SYNTHETIC_FPS = 30.0     # frame rate of `synthetic:` clips and .npy frame stacks (they carry none)
+
+
+def time_to_frame(time_seconds, fps):
+    """Seconds -> frame number, the reference's rule (flow_processor.py:137-139, video/video_info.py:80-93)."""
+    if fps <= 0:
+        raise ValueError("Cannot convert time to frame: invalid FPS")
+    return int(time_seconds * fps)
+
+
+def validate_frame_range(start_frame, frame_count, total_frames):
+    """The reference's clamp (video/video_info.py:110-132): negative starts become 0, a start past the end is an
+    error, the count is cut to what the clip holds."""
+    if start_frame < 0:
+        start_frame = 0
+    elif start_frame >= total_frames:
+        raise ValueError(f"Start frame {start_frame} exceeds total frames {total_frames}")
+    return start_frame, min(frame_count, total_frames - start_frame)
+
+
+def probe_input(spec):
+    """-> (fps, total_frames) of an input without decoding it."""
+    if spec.startswith('synthetic:'):
+        w, h, n = (int(v) for v in spec.split(':', 1)[1].lower().split('x'))
+        return SYNTHETIC_FPS, n
+    if spec.endswith('.npy'):
+        return SYNTHETIC_FPS, int(np.load(spec, mmap_mode='r').shape[0])
+    try:
+        import cv2
+    except ImportError:
+        raise SystemExit(f"Cannot decode {spec}: OpenCV is not installed. Use a .npy frame stack or synthetic:WxHxF.")
+    cap = cv2.VideoCapture(spec)
+    fps, n = cap.get(cv2.CAP_PROP_FPS), int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+    cap.release()
+    return fps, n
+
+
+def resolve_frame_range(spec, start_frame, max_frames, start_time=None, duration=None, log=print):
+    """--start-time / --duration -> (start_frame, max_frames) exactly as the reference converts them
+    (flow_processor.py:667-677, :1403-1420; video/frame_extractor.py:88-98): `int(seconds * fps)` replaces the frame
+    arguments, then the range is clamped to the clip.  The resolved pair is what the cache directory is named after
+    (storage/filename_generator.py: `_start{s}_frames{n}`)."""
+    fps, total = probe_input(spec)
+    if start_time is not None or duration is not None:
+        log(f"Video FPS: {fps:.2f}")
+        if start_time is not None:
+            start_frame = time_to_frame(start_time, fps)
+            log(f"Start time: {start_time}s -> frame {start_frame}")
+        if duration is not None:
+            max_frames = time_to_frame(duration, fps)
+            log(f"Duration: {duration}s -> {max_frames} frames")
+    return validate_frame_range(start_frame, max_frames, total)
+
+
+def load_frames(spec, start_frame, max_frames, fps_default=SYNTHETIC_FPS):
     """-> (frames list of uint8 [H,W,3], fps, width, height, start_frame): the 5-tuple shape of the
     reference's FrameExtractor.extract_frames (video/frame_extractor.py:139)."""
     if spec.startswith('synthetic:'):
@@ -116,7 +170,16 @@ def main(argv=None):
     if device == 'cuda' and world > 1:
         torch.cuda.set_device(local_rank)
         device = f"cuda:{local_rank}"
-    frames, fps, width, height, start = load_frames(args.input, args.start_frame, args.frames)
+    try:
+        start_frame, max_frames = resolve_frame_range(args.input, args.start_frame, args.frames, args.start_time,
+                                                      args.duration, log)
+    except ValueError as e:
+        log(f"Error: {e}")
+        return 1
+    if max_frames <= 0:
+        log(f"Error: empty frame range (start {start_frame}, {max_frames} frames)")
+        return 1
+    frames, fps, width, height, start = load_frames(args.input, start_frame, max_frames)
     n = len(frames)
     mgr = FlowCacheManager()
     cache_src = args.input if not args.input.startswith('synthetic:') else os.path.join(args.output, args.input.replace(':', '_') + ".npy")
@@ -137,15 +200,18 @@ def main(argv=None):
                                  args.vf_architecture, args.vf_variant)
     eng.load_model()
     proc = eng.get_processor()
-    clip = proc.upload_clip(frames)
+    feeder = ClipFeeder(frames, device)     # frames go up through a pinned ring while earlier fields compute
     save_format = args.save_flow or 'npz'
     # rank 0 owns the cache files; the writer's threads compress finished fields while the GPU computes the
     # next ones (one rank, whole frames) or after the gather (several ranks / tiles)
     writer = AsyncFlowCacheWriter(cache_dir, save_format, workers=min(16, os.cpu_count() or 1),
                                   num_lods=0 if args.skip_lods else 5, manager=mgr) if rank == 0 else None
     t0 = time.time()
-    run_sharded(proc, clip, range(n), tile_mode=args.tile and not memflow, rank=rank, world=world,
-                on_field=(lambda k, field: writer.submit(field, k)) if writer is not None else None)
+    # LOD levels are reduced on the GPU that computed the field (bit-identical to the reference's loop) and travel
+    # with it; tiled frames are assembled on rank 0 and reduced by the writer's threads
+    run_sharded(proc, None, range(n), tile_mode=args.tile and not memflow, rank=rank, world=world, feeder=feeder,
+                on_field=(lambda k, field, lods: writer.submit(field, k, lods)) if writer is not None else None,
+                collect=False, num_lods=0 if (args.skip_lods or save_format == 'flo') else 5)
     if str(device).startswith('cuda'):
         torch.cuda.synchronize()
     dt = time.time() - t0

@@ -15,6 +15,7 @@ import torch
 
 from vfml import InputPadder
 from vfml.memflow_net import build_memflow_network, memflow_cfg
+from vfml.weights import load_checked
 
 
 class MemFlowCore:
@@ -49,10 +50,10 @@ class MemFlowCore:
             cfg = memflow_cfg()
             cfg.restore_ckpt = self.model_path
             model = build_memflow_network(cfg)
-            state = torch.load(self.model_path, map_location=self.device)
+            state = torch.load(self.model_path, map_location=self.device, weights_only=True)
             if any(k.startswith('module.') for k in state):
                 state = {k.replace('module.', ''): v for k, v in state.items()}
-            model.load_state_dict(state)
+            load_checked(model, state, self.model_path)
             self.model = model.to(self.device).eval()
             self.cfg = cfg
         except Exception as e:

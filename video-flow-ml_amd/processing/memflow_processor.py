@@ -68,19 +68,24 @@ class MemFlowProcessor:
 
     # -- HBM-resident clips (extension; same fields as compute_optical_flow) -------------------------
     def upload_clip(self, frames):
+        from vfml.clip_id import clip_token
         host = torch.from_numpy(np.stack(frames))
         dev = self.core_engine.device
         if dev.startswith('cuda'):
             host = host.pin_memory()
-        return host.to(dev, non_blocking=True)
+        clip = host.to(dev, non_blocking=True)
+        clip_token(clip)          # a fresh identity per upload (vfml/clip_id.py)
+        return clip
 
     def compute_optical_flow_resident(self, clip, frame_idx, tile=None):
         """uint8 clip [F,H,W,3] on the device -> flow [H,W,2] on the device (tile is ignored: MemFlow
         works on full frames, reference :190-247)."""
+        from vfml.clip_id import clip_token
         from vfml.network import take_frames
         ids = self.window_indices(frame_idx)
         x = take_frames(clip, ids).permute(0, 3, 1, 2).float().unsqueeze(0)
-        keys = [(clip.data_ptr(), clip._version, i) for i in ids]      # same clip, same frame = same pixels
+        tok = clip_token(clip)
+        keys = [(tok, i) for i in ids]      # same clip, same frame = same pixels
         return self.core_engine.compute_flow_from_tensor(x, keep_on_device=True, frame_keys=keys).permute(1, 2, 0)
 
     PAIR_BATCH = int(os.environ.get("VFML_PAIR_BATCH", "3"))   # fields per pass of the engine in job loops
@@ -88,7 +93,11 @@ class MemFlowProcessor:
     def _frame_maxima(self, clip):
         """Largest value of every frame of a resident clip (one pass + one sync per clip): the range heuristic
         of the reference's script looks at the window's maximum."""
-        key = (clip.data_ptr(), clip._version, tuple(clip.shape))
+        from vfml.clip_id import clip_token
+        fed = getattr(clip, "_vfml_frame_maxima", None)      # a clip fed frame by frame knows them from the host side
+        if fed is not None:
+            return fed
+        key = (clip_token(clip), tuple(clip.shape))
         if getattr(self, "_maxima_key", None) != key:
             self._maxima = clip.reshape(clip.shape[0], -1).amax(dim=1).tolist()
             self._maxima_key = key
@@ -98,6 +107,7 @@ class MemFlowProcessor:
         """Fields of several frames of a resident clip -> list of device tensors [H,W,2].  Runs of consecutive
         frames (pairs (i-1, i), same branch of the range heuristic) go through the engine PAIR_BATCH at a time;
         frame 0 (pair (0, 0)) and anything irregular one by one.  Same fields as compute_optical_flow_resident."""
+        from vfml.clip_id import clip_token
         from vfml.network import take_frames
         frame_idxs = list(frame_idxs)
         model = self.core_engine.model
@@ -122,7 +132,8 @@ class MemFlowProcessor:
             else:
                 ids = list(range(i - 1, frame_idxs[e] + 1))                      # B + 1 consecutive frames
                 x = take_frames(clip, ids).permute(0, 3, 1, 2).float().unsqueeze(0)
-                keys = [(clip.data_ptr(), clip._version, j) for j in ids]
+                tok = clip_token(clip)
+                keys = [(tok, j) for j in ids]
                 flows = self.core_engine.compute_pair_flows(x, mode_of(i), frame_keys=keys)
                 out.extend(flows[j].permute(1, 2, 0) for j in range(flows.shape[0]))
             k = e + 1

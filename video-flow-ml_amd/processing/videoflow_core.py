@@ -9,7 +9,7 @@ import os
 import torch
 
 from vfml import InputPadder, build_network, get_cfg
-from vfml.weights import checkpoint_name
+from vfml.weights import checkpoint_name, load_checked
 
 
 def _is_gpu_name(dev: str) -> bool:
@@ -42,10 +42,11 @@ class VideoFlowCore:
             raise FileNotFoundError(f"VideoFlow model weights not found: {model_path}")
         self.cfg = cfg
         model = build_network(cfg)
-        state = torch.load(model_path, map_location=self.device)
+        # weights_only: a third-party .pth never gets to run pickle code (torch >= 2.6 defaults to it, older did not)
+        state = torch.load(model_path, map_location=self.device, weights_only=True)
         if any(k.startswith('module.') for k in state):   # DataParallel checkpoints (:106-108)
             state = {k.replace('module.', ''): v for k, v in state.items()}
-        model.load_state_dict(state)
+        load_checked(model, state, model_path)
         model.to(self.device)
         model.eval()
         self.model = model

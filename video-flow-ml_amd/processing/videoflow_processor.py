@@ -184,16 +184,20 @@ class VideoFlowProcessor:
         the reference re-uploads T float32 frames per field, 4x the bytes and T-1 of them repeats)."""
         if any(f.dtype != np.uint8 for f in frames):
             raise ValueError("upload_clip expects uint8 frames")
+        from vfml.clip_id import clip_token
         host = torch.from_numpy(np.stack(frames))
         if str(self.device).startswith('cuda'):
             host = host.pin_memory()
-        return host.to(self.device, non_blocking=True)
+        clip = host.to(self.device, non_blocking=True)
+        clip_token(clip)          # a fresh identity per upload: cache keys never follow a recycled address
+        return clip
 
     def compute_optical_flow_resident(self, clip, frame_idx, tile=None):
         """Flow field of `frame_idx` from a clip already in HBM -> device tensor [H,W,2] float32.
         Same window, same /255, same network and index pick as compute_optical_flow; the u8->float
         conversion runs inside the engine's first kernel."""
         self._require_model()
+        from vfml.clip_id import clip_token
         from vfml.network import take_frames
         frame_ids = self.window_indices(clip.shape[0], frame_idx)
         win = take_frames(clip, frame_ids)        # a view in the steady state: no index upload, no sync
@@ -206,7 +210,8 @@ class VideoFlowProcessor:
         if H % 8 == 0 and W % 8 == 0 and hasattr(model, "forward_u8"):
             # a frame of this clip (and tile) is the same pixels in every window that contains it:
             # let the engine reuse its per-frame encoder outputs across the sliding windows
-            keys = [(clip.data_ptr(), clip._version, i, rect) for i in frame_ids]
+            tok = clip_token(clip)
+            keys = [(tok, i, rect) for i in frame_ids]
             flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=keys, pick_only=self.PICK_ONLY)
             return flows[0, flows.shape[1] // 2].permute(1, 2, 0)
         batch = (win.float() / 255.0).permute(0, 3, 1, 2).unsqueeze(0)
@@ -219,6 +224,7 @@ class VideoFlowProcessor:
         triple keeps a third of the chip busy.  Everything else falls back to one call per frame.  Same
         fields as compute_optical_flow_resident, bit for bit."""
         self._require_model()
+        from vfml.clip_id import clip_token
         from vfml.network import take_frames
         model = self.core.model
         frame_idxs = list(frame_idxs)
@@ -238,7 +244,8 @@ class VideoFlowProcessor:
             else:
                 B = e - k + 1
                 ids = list(range(triples[k][0], triples[e][2] + 1))              # B + 2 consecutive frames
-                keys = [(clip.data_ptr(), clip._version, i, None) for i in ids]
+                tok = clip_token(clip)
+                keys = [(tok, i, None) for i in ids]
                 flows, _ = model.forward_u8(take_frames(clip, ids), return_lowres=False, frame_keys=keys, tri_batch=True)
                 out.extend(flows[0, B + j].permute(1, 2, 0) for j in range(B))
             k = e + 1

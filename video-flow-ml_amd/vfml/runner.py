@@ -1,10 +1,18 @@
 """Sharded flow-field job: the loop of reference flow_processor.py:959-976 / :1460-1470
-(`for i in frames: compute_optical_flow[_tiled]`) spread over the GPUs of one node.
+(`for i in frames: compute_optical_flow[_tiled]`) spread over the GPUs of one node, host memory to host memory.
 
 Work items are (frame) or (frame, tile); ranks take contiguous blocks (vfml.dist.shard_bounds), keep
-the clip resident in their own HBM, compute with no data-path communication, and one gather brings
-the finished fields to rank 0, which pastes tiles with the reference's hard seams
-(processing/videoflow_processor.py:277) and owns the cache files."""
+the clip resident in their own HBM and compute with no data-path communication.  Finished fields STREAM to
+rank 0 while the job runs: every `chunk` items each rank contributes its newest fields to one gather (RCCL over
+xGMI; gloo in the CPU tests) that runs beside the computation of the next chunk, rank 0 copies the received
+chunk to pinned host memory on a side stream, pastes tiles with the reference's hard seams
+(processing/videoflow_processor.py:277) and hands every finished frame to `on_field` (the cache writer).
+Rank 0 therefore holds two chunks of receive buffers, not the whole job, and the tail of a job is one chunk
+long.  With one rank the gather is the identity and the same pipeline is the D2H ring of a single GPU.
+
+Input side: `ClipFeeder` uploads the uint8 frames from (pageable) host memory through a pinned ring on a side
+stream, a few frames ahead of the window being computed, so the clip never has to be stacked, pinned and
+uploaded as a whole before the first field starts."""
 import numpy as np
 import torch
 
@@ -20,97 +28,257 @@ def item_numel(height, width, tile):
     return h * w * 2
 
 
-def _run_streaming(proc, clip, frame_indices, on_field):
-    """One rank, whole frames: every field goes to host memory as soon as it is finished (pinned staging
-    ring, the copy of field i overlaps the computation of field i+1) and is handed to `on_field(k, array)`
-    - the cache writer of flow_processor.py - while the GPU keeps computing."""
-    H, W = clip.shape[1], clip.shape[2]
-    out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32)
-    on_gpu = clip.is_cuda
-    ring = [torch.empty((H, W, 2), dtype=torch.float32).pin_memory() for _ in range(3)] if on_gpu else None
-    events = [None] * 3
-    pending = []                                       # (slot in out, ring index)
-
-    def drain(limit):
-        while len(pending) > limit:
-            k, r = pending.pop(0)
-            events[r].synchronize()
-            out[k] = ring[r].numpy()
-            on_field(k, out[k])
-
-    for k, flow in _fields_in_order(proc, clip, frame_indices):
-        if not on_gpu:
-            out[k] = flow.numpy()
-            on_field(k, out[k])
-            continue
-        drain(2)                                       # the ring slot about to be reused is free
-        r = k % 3
-        ring[r].copy_(flow, non_blocking=True)
-        events[r] = torch.cuda.Event()
-        events[r].record()
-        pending.append((k, r))
-        drain(1)                                       # hand over field k-1 while field k is in flight
-    drain(0)
+def lod_shapes(height, width, num_lods):
+    """[(h, w)] of LOD levels 1..num_lods-1 of a field (each level halves both sides, rounding up:
+    reference storage/cache_manager.py:77-161)."""
+    out, h, w = [], height, width
+    for _ in range(1, max(1, num_lods)):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        out.append((h, w))
     return out
 
 
-def _fields_in_order(proc, clip, frame_indices):
+class ClipFeeder:
+    """Device-resident uint8 clip [F,H,W,3] filled frame by frame from host arrays, ahead of use.
+
+    `ensure(upto)` makes frames 0..upto usable by work queued on the current stream afterwards: frames not yet
+    uploaded are copied into a pinned ring (host memcpy, 1 ms per 1080p frame) and from there to the device on a
+    side stream; the current stream waits for those copies only.  The reference uploads T float32 frames per
+    field from pageable memory (processing/videoflow_processor.py:161); here every frame crosses PCIe once, as
+    uint8, while the GPU computes earlier fields."""
+
+    RING = 4
+
+    def __init__(self, frames, device):
+        f0 = frames[0]
+        self.device = torch.device(device)
+        self.clip = torch.empty((len(frames),) + tuple(f0.shape), dtype=torch.uint8, device=self.device)
+        self.on_gpu = self.device.type == "cuda"
+        if self.on_gpu:
+            self.ring = [torch.empty(tuple(f0.shape), dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+            self.ring_np = [r.numpy() for r in self.ring]
+            self.events = [None] * self.RING
+            self.stream = torch.cuda.Stream(device=self.device)
+        self.reset(frames)
+
+    def reset(self, frames):
+        """Start over with another list of frames of the same shape and count (the buffers are kept; the clip gets
+        a new identity, so nothing cached for the old frames is found under the new ones)."""
+        from .clip_id import new_id
+        f0 = frames[0]
+        if (any(f.dtype != np.uint8 or f.shape != f0.shape for f in frames) or len(frames) != self.clip.shape[0]
+                or tuple(f0.shape) != tuple(self.clip.shape[1:])):
+            raise ValueError("ClipFeeder expects uint8 frames of one shape (and, on reset, the shape it was built for)")
+        self.frames = frames
+        self.next = 0
+        # a frame never changes once it is uploaded: the token is fixed although uploads move clip._version
+        self.clip._vfml_clip_token = (new_id(), "fed")
+        # per-frame maxima, known at upload: MemFlow's value-range heuristic (memflow_inference_isolated.py:81-85)
+        self.clip._vfml_frame_maxima = [None] * len(frames)
+        if self.on_gpu:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # earlier readers of the old frames
+
+    def ensure(self, upto):
+        upto = min(upto, len(self.frames) - 1)
+        if upto < self.next:
+            return
+        maxima = self.clip._vfml_frame_maxima
+        if not self.on_gpu:
+            for f in range(self.next, upto + 1):
+                self.clip[f] = torch.from_numpy(np.ascontiguousarray(self.frames[f]))
+                maxima[f] = float(self.frames[f].max())
+            self.next = upto + 1
+            return
+        last = None
+        for f in range(self.next, upto + 1):
+            r = f % self.RING
+            maxima[f] = float(self.frames[f].max())
+            if self.events[r] is not None:
+                self.events[r].synchronize()          # the slot's previous upload has left the pinned buffer
+            np.copyto(self.ring_np[r], self.frames[f])
+            with torch.cuda.stream(self.stream):
+                self.clip[f].copy_(self.ring[r], non_blocking=True)
+                last = torch.cuda.Event()
+                last.record(self.stream)
+            self.events[r] = last
+        self.next = upto + 1
+        torch.cuda.current_stream(self.device).wait_event(last)    # (copies on one stream complete in order)
+
+
+def _fields_in_order(proc, clip, frame_indices, before=None):
     """(position, field) for every frame, whole frames: a few fields per pass where the processor can batch
     them (the tri-frame network, compute_optical_flow_resident_batch), else one call per field."""
     batch = getattr(proc, "compute_optical_flow_resident_batch", None)
     step = (getattr(proc, "TRI_BATCH", None) or getattr(proc, "PAIR_BATCH", 1)) if batch is not None else 1
     for k0 in range(0, len(frame_indices), step):
         chunk = frame_indices[k0:k0 + step]
+        if before is not None:
+            before(max(chunk))
         flows = batch(clip, chunk) if batch is not None else [proc.compute_optical_flow_resident(clip, f) for f in chunk]
         for j, flow in enumerate(flows):
             yield k0 + j, flow
 
 
-def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None, on_field=None):
-    """Compute the flow field of every frame in `frame_indices` of the device-resident uint8 clip
-    [F,H,W,3].  Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2]; None elsewhere.
-    `on_field(k, field)` (optional) is called on rank 0 for every finished field, k = position in
-    `frame_indices`: as the fields finish when one rank computes whole frames, after the gather otherwise."""
+def default_chunk(slot_floats, n_items, world):
+    """Items per chunk: one with a single rank (the D2H of a field then hides under the next field), two with
+    several (one collective per two fields of every rank; fewer when an item exceeds 64 MB)."""
+    if world == 1:
+        return 1
+    return int(max(1, min(2, (128 << 20) // max(1, 4 * slot_floats), n_items)))
+
+
+def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None, on_field=None,
+                collect=True, num_lods=0, chunk=None, feeder=None):
+    """Compute the flow field of every frame in `frame_indices` of the device-resident uint8 clip [F,H,W,3]
+    (`clip` may be None when a ClipFeeder is given: its clip is used and fed as the job advances).
+    Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2] (None with collect=False, when the
+    fields only go to `on_field`); None on the other ranks.
+    `on_field(k, field, lods)` is called on rank 0 for every finished frame as soon as it (in tile mode: its last
+    tile) has reached host memory, k = position in `frame_indices`; `field` is a host array the callee may keep;
+    `lods` is None or, with num_lods > 1 (whole frames only), the reference's LOD pyramid [field, lod1, ...] reduced
+    on the GPU that computed the field (vfml_flow_lod, bit-identical to the reference's loop)."""
     frame_indices = list(frame_indices)
+    if feeder is not None:
+        clip = feeder.clip
     F, H, W = clip.shape[0], clip.shape[1], clip.shape[2]
-    if on_field is not None and world == 1 and not tile_mode:
-        return _run_streaming(proc, clip, frame_indices, on_field)
     tiles = _tiles(proc, W, H, tile_mode)
+    whole = len(tiles) == 1
+    on_gpu = clip.is_cuda
+    lods_on = num_lods > 1 and whole and on_gpu
+    lshapes = lod_shapes(H, W, num_lods) if lods_on else []
     items = vdist.work_items(frame_indices, len(tiles), tile_major=True)   # keeps the per-crop caches hot
     bounds = [vdist.shard_bounds(len(items), r, world) for r in range(world)]
-    sizes = [sum(item_numel(H, W, tiles[t]) for _, t in items[lo:hi]) for lo, hi in bounds]
+    counts = [hi - lo for lo, hi in bounds]
     lo, hi = bounds[rank]
-    local = torch.empty(sizes[rank], dtype=torch.float32, device=clip.device)
-    off = 0
-    if len(tiles) == 1:                                # whole frames: batched where the processor can
-        for _, flow in _fields_in_order(proc, clip, [f for f, _ in items[lo:hi]]):
-            n = flow.numel()
-            local[off:off + n].copy_(flow.reshape(-1))
-            off += n
-    else:
-        for f, t in items[lo:hi]:
-            flow = proc.compute_optical_flow_resident(clip, f, tile=tiles[t])
-            n = flow.numel()
-            local[off:off + n].copy_(flow.reshape(-1))
-            off += n
-    parts = vdist.gather_to_rank0(local, sizes, group=group)
-    if rank != 0:
-        return None
-    out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32)
-    slot = {f: k for k, f in enumerate(frame_indices)}
-    for (blo, bhi), part in zip(bounds, parts):
-        host = part.cpu().numpy()
-        off = 0
-        for f, t in items[blo:bhi]:
-            tile = tiles[t]
-            n = item_numel(H, W, tile)
-            if tile is None:
-                out[slot[f]] = host[off:off + n].reshape(H, W, 2)
+    mine = items[lo:hi]
+    slot = max([item_numel(H, W, t) for t in tiles]) + sum(h * w * 2 for h, w in lshapes)
+    K = chunk or default_chunk(slot, max(counts) if counts else 1, world)
+    n_chunks = -(-max(counts) // K) if counts and max(counts) > 0 else 0
+    dev = clip.device
+    send = [torch.empty((K, slot), dtype=torch.float32, device=dev) for _ in range(min(2, n_chunks))]
+    recv = host = None
+    if rank == 0 and n_chunks:
+        if world > 1:
+            recv = [[torch.empty((K, slot), dtype=torch.float32, device=dev) for _ in range(world)]
+                    for _ in range(min(2, n_chunks))]
+        shape = (world, K, slot)
+        host = [torch.empty(shape, dtype=torch.float32).pin_memory() if on_gpu else torch.empty(shape, dtype=torch.float32)
+                for _ in range(min(2, n_chunks))]
+    side = torch.cuda.Stream(device=dev) if on_gpu and rank == 0 else None
+    seq = getattr(proc, "sequence_length", 1)
+
+    out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32) if (rank == 0 and collect) else None
+    slot_of = {f: k for k, f in enumerate(frame_indices)}
+    partial, left = {}, {}                                  # tile mode without `collect`: frames being assembled
+
+    def feed(frame):
+        if feeder is not None:
+            feeder.ensure(frame + seq)                      # the window's last frame and a few ahead
+
+    def compute_chunk(c, sbuf):
+        part = mine[c * K:(c + 1) * K]
+        if not part:
+            return
+        if whole:
+            for j, flow in _fields_in_order(proc, clip, [f for f, _ in part], before=feed):
+                row = sbuf[j]
+                n = H * W * 2
+                row[:n].copy_(flow.reshape(-1))
+                if lods_on:
+                    from . import hip
+                    off = n
+                    for lvl in hip.flow_lods(row[:n].view(H, W, 2), num_lods)[1:]:
+                        row[off:off + lvl.numel()].copy_(lvl.reshape(-1))
+                        off += lvl.numel()
+        else:
+            for j, (f, t) in enumerate(part):
+                feed(f)
+                flow = proc.compute_optical_flow_resident(clip, f, tile=tiles[t])
+                sbuf[j, :flow.numel()].copy_(flow.reshape(-1))
+
+    def deliver(k, field, lods):
+        if on_field is not None:
+            on_field(k, field, lods)
+
+    def unpack(c, hbuf):
+        """rank 0: chunk c of every rank, now in host memory -> frames / callbacks."""
+        harr = hbuf.numpy()
+        for r in range(world):
+            blo = bounds[r][0]
+            for j in range(min(K, counts[r] - c * K)):
+                f, t = items[blo + c * K + j]
+                k = slot_of[f]
+                row = harr[r, j]
+                tile = tiles[t]
+                n = item_numel(H, W, tile)
+                if tile is None:
+                    if out is not None:
+                        out[k] = row[:n].reshape(H, W, 2)
+                        field = out[k]
+                    else:
+                        field = row[:n].reshape(H, W, 2).copy()       # the pinned chunk buffer is reused
+                    lods = None
+                    if lods_on:
+                        lods, off = [field], n
+                        for h, w in lshapes:
+                            lods.append(row[off:off + h * w * 2].reshape(h, w, 2).copy())
+                            off += h * w * 2
+                    deliver(k, field, lods)
+                else:
+                    y, x, th, tw = tile['y'], tile['x'], tile['height'], tile['width']
+                    if out is not None:
+                        frame = out[k]
+                    else:
+                        frame = partial.get(k)
+                        if frame is None:
+                            frame = partial[k] = np.zeros((H, W, 2), dtype=np.float32)
+                    frame[y:y + th, x:x + tw] = row[:n].reshape(th, tw, 2)
+                    left[k] = left.get(k, len(tiles)) - 1
+                    if left[k] == 0:
+                        partial.pop(k, None)
+                        deliver(k, frame, None)
+
+    def finish(c, work, ev_done):
+        """Chunk c has been queued (and its gather started): bring it to the host and unpack it.  The GPU already
+        has the next chunk's kernels queued, so the host waits here while the device stays busy."""
+        b = c % 2
+        if world > 1 and rank != 0:
+            work.wait()                                     # before this send buffer is written again
+            return
+        if not on_gpu:
+            if world > 1:
+                work.wait()
+                host[b].copy_(torch.stack(recv[b]))
             else:
-                y, x, th, tw = tile['y'], tile['x'], tile['height'], tile['width']
-                out[slot[f], y:y + th, x:x + tw] = host[off:off + n].reshape(th, tw, 2)
-            off += n
-    if on_field is not None:
-        for k in range(len(frame_indices)):
-            on_field(k, out[k])
+                host[b][0].copy_(send[b])
+            unpack(c, host[b])
+            return
+        with torch.cuda.stream(side):
+            if world > 1:
+                work.wait()                                 # the side stream waits for the collective
+                for r in range(world):
+                    host[b][r].copy_(recv[b][r], non_blocking=True)
+            else:
+                side.wait_event(ev_done)
+                host[b][0].copy_(send[b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        ev.synchronize()
+        unpack(c, host[b])
+
+    prev = None
+    for c in range(n_chunks):
+        b = c % 2
+        compute_chunk(c, send[b])
+        work = ev_done = None
+        if world > 1:
+            work = torch.distributed.gather(send[b], recv[b] if rank == 0 else None, dst=0, group=group, async_op=True)
+        elif on_gpu:
+            ev_done = torch.cuda.Event()
+            ev_done.record()
+        if prev is not None:
+            finish(*prev)
+        prev = (c, work, ev_done)
+    if prev is not None:
+        finish(*prev)
     return out

@@ -82,6 +82,34 @@ def seeded_state_dict(cfg, seed=0):
     return sd
 
 
+def load_checked(model, state, what):
+    """Strict `load_state_dict` (reference processing/videoflow_core.py:110) with an error that names what does not
+    fit: the engine hard-codes the RAFT BasicEncoder key layout (`fnet.conv1`, `fnet.layer1.0.conv1`, ...), while the
+    released MOF / BOF configurations select Twins-SVT encoders (`fnet.svt.*`) - such a checkpoint
+    is refused with its unexpected key FAMILIES listed instead of hundreds of raw keys.  Numerical parity with the
+    published checkpoints is unverified: they are not available here (.MISSING_LARGE_BLOBS)."""
+    want = set(model.state_dict().keys())
+    have = set(state.keys())
+    if want != have:
+        def families(keys):
+            fam = {}
+            for k in keys:
+                parts = k.split(".")
+                f = ".".join(parts[:2]) + ".*" if len(parts) > 2 else k
+                fam[f] = fam.get(f, 0) + 1
+            return ", ".join(f"{f} ({n})" for f, n in sorted(fam.items())) or "none"
+        raise RuntimeError(
+            f"{what}: checkpoint does not match the network this engine builds (CNN BasicEncoder fnet/cnet, "
+            f"SepConvGRU update block).  Unexpected key families: {families(have - want)}.  Missing key families: "
+            f"{families(want - have)}.  Checkpoints of the upstream Twins-SVT configurations (fnet.svt.* / cnet.svt.*) "
+            f"are not supported.")
+    bad = [f"{k}: checkpoint {tuple(state[k].shape)} vs network {tuple(v.shape)}"
+           for k, v in model.state_dict().items() if tuple(state[k].shape) != tuple(v.shape)]
+    if bad:
+        raise RuntimeError(f"{what}: parameter shapes differ: " + "; ".join(bad[:8]) + (" ..." if len(bad) > 8 else ""))
+    model.load_state_dict(state)
+
+
 def checkpoint_name(architecture="mof", dataset="sintel", variant="standard"):
     """File name rule of reference processing/videoflow_core.py:79-85."""
     arch = architecture.upper()
