@@ -5,18 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one flow field: MOF_sintel, seq_len=5, 1920x1080, synthetic clip (BASELINE.json configs[1]),
-computed through the drop-in API (processing.VideoFlowProcessor -> VideoFlowCore -> HIP engine) from a
-uint8 clip already resident in HBM, result left in HBM as [H,W,2] float32.  With N>1 every rank
-runs K steps on its own frame range (weak scaling, no data-path collective) and one RCCL gather
-brings the finished fields to rank 0 inside the timed region.  Rank 0 prints ONE JSON line.
+A step = one flow field: MOF_sintel, seq_len=5, 1920x1080, synthetic clip (BASELINE.json configs[1]), computed
+through the drop-in API (processing.VideoFlowProcessor -> VideoFlowCore -> HIP engine) by the job loop of the CLI
+(vfml.runner.run_sharded).
+
+Timed region: uint8 frames resident in HOST memory + model loaded  ->  last field resident in
+rank-0 HOST memory.  Inside it: every new frame goes up through the pinned ring (ClipFeeder), K fields are computed
+per rank, each field is copied to pinned host memory while the next one computes, and with N > 1 the ranks' fields
+stream to rank 0 in chunked RCCL gathers beside the computation (weak scaling: K fields per rank, no data-path
+collective).  W warm-up fields of the same sliding job run before it, so the timed fields are the steady state of a
+long job (one new frame per field).  `engine_ms_per_step` is the same loop with inputs and outputs left in HBM.
 
 Extra objects on the line:
-  roofline      dominant kernel (the split-f16 LDS-DMA implicit-GEMM conv), achieved algorithmic TFLOP/s from HIP
-                events recorded around its launches inside the timed region vs 2500 / 3 TFLOP/s (three f16 MFMAs
-                per product); `traffic`: HBM-side bytes per launch from the PMC passes recorded in
-                profiles/r01_j_hbm_traffic.json beside `algorithmic_bytes_per_launch`; `hbm_kernels`: the lookup
-  cpu_baseline  the CPU oracle (oracle/mof_oracle.py, "port") timed on this box's host cores on a
+  roofline      dominant kernel, from a SEPARATE pass after the timed region (per-launch HIP events on the launch
+                stream perturb the timing, so they never run inside `value`): achieved algorithmic TFLOP/s vs the dense
+                f16 MFMA peak / MFMAs per product; `traffic`: HBM-side bytes per launch from the PMC passes recorded
+                under profiles/ (a stored constant of that profile run, labelled so); `hbm_kernels`: the lookup
+  cpu_baseline  the CPU oracle (oracle/mof_oracle.py, "port") timed on this box's host cores BEFORE the timed region on a
                 bounded sample of the same workload (N=1 only), plus the engine-vs-oracle EPE on it
 """
 import argparse
@@ -33,26 +38,37 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# MI355X_MICROARCH.md, dense matrix peaks.  The default arithmetic ("f16x3") spends three
-# v_mfma_f32_32x32x16_f16 per fp32-grade product, so its ceiling in ALGORITHMIC FLOP/s is a third of
-# the f16 MFMA peak; "f32" runs v_mfma_f32_32x32x2_f32 and is priced against the f32 matrix peak.
+# MI355X_MICROARCH.md, dense matrix peaks.  'f16x3' spends three v_mfma_f32_32x32x16_f16 per fp32-grade product, so
+# its ceiling in ALGORITHMIC FLOP/s is a third of the f16 MFMA peak (a half / the whole of it for layers that run with
+# two / one MFMA per product); 'f32' runs v_mfma_f32_32x32x2_f32 and is priced against the f32 matrix peak.
 F16_MATRIX_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
 F32_MATRIX_PEAK_TFLOPS = 157.3
+
+DTYPE_NOTE = {
+    "f16x3": "f16x3 (split-f16 MFMA: 3 f16 MFMAs per product, f32 accumulate, fp32-grade)",
+    "f16x2": "f16x2 (weights as plain f16: 2 f16 MFMAs per product, f32 accumulate)",
+    "f16": "f16 (plain f16 MFMA operands, f32 accumulate)",
+    "f32": "f32",
+}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--seq", type=int, default=5)
     ap.add_argument("--workload", default="mof1080p", choices=["mof1080p", "mof4k-tile", "memflow1080p", "bof720p"],
                     help="mof1080p = BASELINE.json configs[1] (the headline, default); the others are the remaining "
                          "GPU configs, measured with the same protocol for DESIGN.md (not the driver's line)")
+    ap.add_argument("--precision", default=None, choices=["f16x3", "f16x2", "f16", "mixed", "f32"],
+                    help="arithmetic of the engine (vfml/cfg.py); default: f16x3, and f16 for bof720p (BASELINE config 5 "
+                         "is quoted in fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the separate per-launch timing pass")
     ap.add_argument("--full-output", action="store_true",
                     help="compute all 2(T-2) flows of the model output per field instead of the one the reference "
                          "path keeps ([0, shape[1]//2]); the default drops, in the last two iterations, the centre "
@@ -60,9 +76,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads for the CPU baseline (0 = this process's CPU share: affinity / cgroup quota, "
                          "capped at 16 - the per-GPU share of the pool's boxes)")
-    ap.add_argument("--cpu-sample-height", type=int, default=0,
-                    help="CPU-baseline sample: 0 = one full-size field (minutes of CPU time), else one field on a "
-                         "centre crop of this height (16:9), scaled to full size by the analytic FLOP ratio")
+    ap.add_argument("--cpu-sample-height", type=int, default=816,
+                    help="CPU-baseline sample: one field on a centre crop of this height (16:9; 816 -> 1440x816, about "
+                         "15 s of CPU work), scaled to full size by the analytic FLOP ratio; 0 = one full-size field "
+                         "(about 40 s)")
     args = ap.parse_args()
 
     if args.workload == "mof4k-tile":
@@ -75,7 +92,11 @@ def main():
         args.no_cpu_baseline = True
     if args.full_output:
         os.environ["VFML_FULL_OUTPUT"] = "1"      # read by processing/videoflow_processor.py at import
+    precision = args.precision or ("f16" if args.workload == "bof720p" else None)
+    if precision and args.workload != "memflow1080p":
+        os.environ["VFML_PRECISION"] = precision  # read by VideoFlowCore
     from vfml import dist as vdist, get_cfg, hip
+    from vfml.runner import ClipFeeder, run_sharded
     from vfml.synth import synthetic_clip
     from vfml.weights import write_seeded_checkpoint
 
@@ -115,68 +136,97 @@ def main():
                                       dataset="things" if arch == "bof" else "sintel", architecture=arch)
         proc.load_model()
     os.chdir(cwd)
-    tiles = proc.calculate_tile_grid(args.width, args.height)[4] if args.workload == "mof4k-tile" else [None]
+    tile_mode = args.workload == "mof4k-tile"
+    core = proc.core if hasattr(proc, "core") else proc.core_engine
 
-    def run_fields(clip, idxs, dst):
-        """Flow fields of frames `idxs` into dst[k] ([H,W,2] each, on the device); in --tile mode
-        tile-major (all fields of tile 0, then tile 1, ...: the order vfml.runner uses), so that
-        consecutive items share their crop's cached frames."""
-        if tiles == [None] and hasattr(proc, "compute_optical_flow_resident_batch"):
-            step = getattr(proc, "TRI_BATCH", None) or getattr(proc, "PAIR_BATCH", 1)   # (several fields per call where it can)
-            for k0 in range(0, len(idxs), step):
-                for j, f in enumerate(proc.compute_optical_flow_resident_batch(clip, idxs[k0:k0 + step])):
-                    dst[k0 + j].copy_(f)
-            return
-        for t in tiles:
-            for k, i in enumerate(idxs):
-                f = proc.compute_optical_flow_resident(clip, i, tile=t)
-                if t is None:
-                    dst[k].copy_(f)
-                else:
-                    dst[k, t['y']:t['y'] + t['height'], t['x']:t['x'] + t['width']].copy_(f)
-
-    # -- synthetic clip, uploaded once ---------------------------------------------------------
+    # -- synthetic clip in host memory; one sliding job per rank: W warm-up fields, K timed, P profiled, E engine-only --
     K, Wm, T = args.steps, args.warmup, args.seq
-    per_rank = K + Wm
-    nframes = per_rank + T - 1
-    # every rank generates the same clip and works on its own window range (frame-range sharding
-    # with a T//2 halo; here the "global" clip is world * per_rank fields long)
+    Pn = 0 if args.no_roofline else min(K, 4)
+    En = min(K, 6)
+    per_rank = Wm + K + Pn + En
+    # the job is one clip of world * per_rank fields; every rank holds it in host memory (same synthetic generator on
+    # every rank - no input exchange) and feeds its own frame range to its GPU as its fields come up
     clip_np = synthetic_clip(world * per_rank + T - 1, args.height, args.width)
-    lo = rank * per_rank
-    clip = proc.upload_clip(clip_np[lo:lo + nframes])
     half = T // 2
-    fields = [half + i for i in range(per_rank)]          # local indices with a full window
+    mine = [rank * per_rank + half + i for i in range(per_rank)]       # this rank's fields (full windows)
+
+    # -- CPU baseline (oracle) on a bounded sample of the same workload: BEFORE anything is timed (and before the
+    #    engine's buffers are sized for the full frame) ----------------------------------------------------------------
+    result_cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        result_cpu = cpu_baseline(args, proc, clip_np, mine[Wm], T)
+        core.model.release_workspace()
+        torch.cuda.empty_cache()
+
+    feeder = ClipFeeder(clip_np, dev)
+
+    def job(idxs, collect=True):
+        """The CLI's job loop on this rank alone (flow_processor.py -> vfml.runner.run_sharded, world 1)."""
+        return run_sharded(proc, None, idxs, tile_mode=tile_mode, rank=0, world=1, feeder=feeder, collect=collect)
+
+    if Wm:
+        job(mine[:Wm], collect=False)
     torch.cuda.synchronize()
 
-    out = torch.empty(max(K, Wm), args.height, args.width, 2, device=dev)
-    run_fields(clip, fields[:Wm], out)
-    torch.cuda.synchronize()
+    # -- timed region: host frames -> fields in rank-0 host memory -----------------------------------------------
+    # the global item list is laid out so that the runner's contiguous shards are the ranks' own K timed fields
+    timed = [r * per_rank + half + Wm + j for r in range(world) for j in range(K)]
+    run_sharded(proc, None, timed, tile_mode=tile_mode, rank=rank, world=world, feeder=feeder, prepare_only=True)
     vdist.barrier(dev)
-
-    out = out[:K]
-    hip.profile_begin()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_fields(clip, fields[Wm:], out)
+    out = run_sharded(proc, None, timed, tile_mode=tile_mode, rank=rank, world=world, feeder=feeder)
     torch.cuda.synchronize()
-    t_compute = time.perf_counter() - t0
-    tg = time.perf_counter()
-    gathered = vdist.gather_to_rank0(out.view(-1), [out.numel()] * world)
-    torch.cuda.synchronize()
-    t_gather = time.perf_counter() - tg
+    t_local = time.perf_counter() - t0
     vdist.barrier(dev)
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof_hbm = hip.profile_end_hbm()
-    prof = hip.profile_end()
     elapsed = vdist.max_over_ranks(elapsed, dev)
+    if rank == 0:
+        assert out is not None and out.shape[0] == K * world and np.isfinite(out[-1]).all() and np.isfinite(out[0]).all()
+    del out
+
+    # -- roofline: separate pass with per-launch HIP events (never inside `value`) -------------------------------
+    prof, prof_hbm, t_prof = {}, {}, None
+    if Pn:
+        torch.cuda.synchronize()
+        e0 = time.perf_counter()
+        if rank == 0:
+            hip.profile_begin()
+        job(mine[Wm + K:Wm + K + Pn], collect=False)       # (every rank does the same work; only rank 0 records)
+        torch.cuda.synchronize()
+        t_prof = time.perf_counter() - e0
+        if rank == 0:
+            prof_hbm = hip.profile_end_hbm()
+            prof = hip.profile_end()
+
+    # -- engine only: the next fields with inputs and outputs left in HBM ----------------------------------------
+    eng_ms = None
+    if En and not tile_mode:
+        idxs = mine[Wm + K + Pn:]
+        feeder.ensure(max(idxs) + T)
+        torch.cuda.synchronize()
+        e0 = time.perf_counter()
+        if hasattr(proc, "compute_optical_flow_resident_batch"):
+            step = getattr(proc, "TRI_BATCH", None) or getattr(proc, "PAIR_BATCH", 1)
+            for k0 in range(0, len(idxs), step):
+                proc.compute_optical_flow_resident_batch(feeder.clip, idxs[k0:k0 + step])
+        else:
+            for i in idxs:
+                proc.compute_optical_flow_resident(feeder.clip, i)
+        torch.cuda.synchronize()
+        eng_ms = 1000.0 * (time.perf_counter() - e0) / len(idxs)
+    vdist.barrier(dev)
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
-    assert gathered is not None and len(gathered) == world
 
     total_fields = K * world
-    core = proc.core if hasattr(proc, "core") else proc.core_engine
     depth = core.cfg.decoder_depth
+    prec = getattr(core.cfg, "precision", "f16x3")
+    dtype = DTYPE_NOTE.get(prec) or ("mixed (per-layer MFMA count, f32 accumulate): " +
+                                     json.dumps(getattr(core.cfg, "mfma_plan", None) or {}, sort_keys=True))
     result = {
         "metric": "flow-fields/sec @1080p seq5 MOF_sintel" if args.workload == "mof1080p"
                   else f"flow-fields/sec {args.workload}",
@@ -187,72 +237,78 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"f16x3": "f16x3 (split-f16 MFMA, f32 accumulate, fp32-grade)", "f32": "f32"}[
-            getattr(core.cfg, "precision", "f16x3")],
+        "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": {"mof1080p": "MOF_sintel", "mof4k-tile": "MOF_sintel --tile (6 tiles/frame)",
                                 "memflow1080p": "MemFlowNet_sintel (pair path)", "bof720p": "BOF_things"}[args.workload]
                                + f" seq_len={T} {args.width}x{args.height} synthetic clip, decoder_depth={depth}, "
                                  f"seeded weights",
-                   "fields_per_gpu": K, "clip_frames_per_gpu": nframes, "parallelism": f"frames-dp{world}",
-                   "inputs": "uint8 clip resident in HBM", "outputs": "[H,W,2] f32 in HBM, gathered to rank 0",
+                   "fields_per_gpu": K, "clip_frames": len(clip_np), "parallelism": f"frames-dp{world}",
+                   "inputs": "uint8 frames in host memory (uploaded inside the timed region through a pinned ring)",
+                   "outputs": "[H,W,2] f32 fields in rank-0 host memory (pinned D2H of field i under field i+1"
+                              + ("; ranks' fields streamed to rank 0 in chunked RCCL gathers)" if world > 1 else ")"),
+                   "steady_state": f"{Wm} warm-up fields of the same sliding job precede the timed fields",
                    "model_output": ("all 2(T-2) flows per field (--full-output)" if args.full_output else
                                     "the flow the reference path keeps, [0, shape[1]//2]; the last two iterations "
                                     "skip the centre frames outside its dependency cone (bit-identical for it; "
                                     "--full-output computes all 2(T-2))")},
-        "compute_ms_per_step": 1000.0 * t_compute / K,
-        "gather_ms": 1000.0 * t_gather,
+        "rank0_local_ms_per_step": 1000.0 * t_local / K,
+        "engine_ms_per_step": eng_ms,       # same job, frames already in HBM, fields left in HBM (a separate pass)
     }
 
     # -- roofline of the dominant kernel -------------------------------------------------------
     if prof:
         name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        split = "split" in name or "dma" in name      # both are split-f16 kernels (3 f16 MFMAs per product)
-        peak = F16_MATRIX_PEAK_TFLOPS / 3.0 if split else F32_MATRIX_PEAK_TFLOPS
+        split = "split" in name or "dma" in name      # the split-f16 kernels; the last template argument = MFMAs per product
+        nm = int(name.rstrip(">").split(",")[-1]) if split else 1
+        peak = F16_MATRIX_PEAK_TFLOPS / nm if split else F32_MATRIX_PEAK_TFLOPS
         traffic, traffic_note = hbm_traffic_from_profiles(name, args.workload)
         result["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak,
             "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
-            "peak_note": ("algorithmic FLOP/s; peak = 2500 TFLOP/s dense f16 MFMA / 3 MFMAs per product"
+            "peak_note": (f"algorithmic FLOP/s; peak = 2500 TFLOP/s dense f16 MFMA / {nm} MFMAs per product"
                           if split else "f32 matrix peak (v_mfma_f32_32x32x2_f32)"),
-            "mfma_executed_tflops": achieved * (3.0 if split else 1.0),
+            "mfma_executed_tflops": achieved * nm,
             "launches": d["launches"], "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
             "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-            "share_of_step": d["ms"] / (1000.0 * t_compute),
+            "pass": f"separate pass over {Pn} further fields of the same job after the timed region, per-launch HIP "
+                    f"events on the launch stream ({1000.0 * t_prof / Pn:.2f} ms per field with the events in)",
+            "share_of_pass": d["ms"] / (1000.0 * t_prof),
             "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                  "launches": v["launches"]} for k, v in prof.items()},
             # the HBM-bound stages of the path beside it: algorithmic bytes / HIP-event time
             "hbm_kernels": {k: {"bound": "hbm", "achieved": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "launches": v["launches"], "avg_launch_us": 1000.0 * v["ms"] / v["launches"],
-                                "share_of_step": v["ms"] / (1000.0 * t_compute)} for k, v in prof_hbm.items()},
+                                "share_of_pass": v["ms"] / (1000.0 * t_prof)} for k, v in prof_hbm.items()},
         }
-
-    # -- CPU baseline (oracle) on a bounded sample of the same workload -------------------------
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, proc, clip_np, fields[Wm], out[0], T)
+    if result_cpu is not None:
+        result["cpu_baseline"] = result_cpu
     print(json.dumps(result))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 def hbm_traffic_from_profiles(kernel, workload):
     """HBM bytes per launch of `kernel` from the PMC passes over this very command (a live run cannot collect them:
-    rocprofv3 has to wrap the process).  profiles/r01_j_hbm_traffic.json holds the per-kernel means of the default
-    workload; None for any other workload or when the file / the kernel is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic.json")
-    if workload != "mof1080p" or not os.path.exists(path):
+    rocprofv3 has to wrap the process).  A STORED CONSTANT of the profile run named in the note, not a measurement of
+    this run; None for any other workload or when no recorded profile has the kernel."""
+    if workload != "mof1080p":
         return None, "no PMC passes recorded for this workload"
-    try:
-        with open(path) as f:
-            rec = json.load(f)["kernels"].get(kernel)
-    except (OSError, ValueError, KeyError):
-        rec = None
-    if not rec:
-        return None, "kernel not in profiles/r01_j_hbm_traffic.json"
-    return rec["hbm_bytes_per_launch"], ("bytes per launch, mean over %d launches: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate "
-                                         "rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1` (profiles/r01_j_hbm_traffic.json)"
-                                         % rec["launches"])
+    pdir = os.path.join(ROOT, "profiles")
+    for fn in sorted((f for f in os.listdir(pdir) if f.endswith("_hbm_traffic.json")), reverse=True):
+        try:
+            with open(os.path.join(pdir, fn)) as f:
+                rec = json.load(f)["kernels"].get(kernel)
+        except (OSError, ValueError, KeyError):
+            rec = None
+        if rec:
+            return rec["hbm_bytes_per_launch"], (
+                "STORED constant, not measured by this run: bytes per launch, mean over %d launches, (2 * FETCH_SIZE + "
+                "WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes over bench.py (profiles/%s)" % (rec["launches"], fn))
+    return None, "kernel not in any profiles/*_hbm_traffic.json"
 
 
 def host_cpu_share(cap=16):
@@ -272,9 +328,9 @@ def host_cpu_share(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(args, proc, clip_np, field_idx, engine_field, T):
+def cpu_baseline(args, proc, clip_np, field_idx, T):
     """The CPU oracle (fp32 PyTorch restatement) on the host cores, on a bounded sample of the
-    workload: one field of the same clip/window/weights, by default on a 960x544 centre crop, scaled
+    workload: one field of the same clip/window/weights, by default on a 1440x816 centre crop, scaled
     to a full-size field by the analytic FLOP ratio (vfml/flops.py; correlation is quadratic in area,
     convolutions linear).  Also returns the engine-vs-oracle end-point error on that sample."""
     from oracle import mof_oracle as mo
@@ -300,13 +356,13 @@ def cpu_baseline(args, proc, clip_np, field_idx, engine_field, T):
     flows, _ = ora(x, {})
     dt = time.perf_counter() - t0
     ref = flows[0, flows.shape[1] // 2].permute(1, 2, 0)
+    dev = next(proc.core.model.parameters()).device
+    eng, _ = proc.core.model.forward_u8(torch.from_numpy(win).to(dev), return_lowres=False)
+    got = eng[0, eng.shape[1] // 2].permute(1, 2, 0).cpu()
     if full:
-        got = engine_field.cpu()
         ratio = 1.0
-        sample = f"1 full {W}x{H} seq{T} field (field {field_idx} of the clip)"
+        sample = f"1 full {W}x{H} seq{T} field (field {field_idx} of the clip, {dt:.1f} s)"
     else:
-        eng, _ = proc.core.model.forward_u8(torch.from_numpy(win).to(engine_field.device), return_lowres=False)
-        got = eng[0, eng.shape[1] // 2].permute(1, 2, 0).cpu()
         ratio = field_work(H, W, T, depth)["total_flops"] / field_work(win.shape[1], win.shape[2], T, depth)["total_flops"]
         sample = (f"1 field on the {win.shape[2]}x{win.shape[1]} centre crop of the window of field {field_idx} "
                   f"({dt:.1f} s), scaled to {W}x{H} by the analytic FLOP ratio {ratio:.2f}")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 14
+#define VFML_ABI_VERSION 15
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -44,7 +44,7 @@ enum {
  *   VFML_FMT_F32  plain NHWC float32.
  *   VFML_FMT_S16  "split rows": same addressing and the same 4 bytes per channel, but every group of
  *                 8 channels (32 bytes, a "unit") holds 8 f16 hi halves then 8 f16 lo halves with
- *                 x = hi + lo (hi = f16(x) toward zero, lo = f16(x - hi)): the operand format of the
+ *                 x = hi + lo (hi = f16(x) rounded to nearest, lo = f16(x - hi)): the operand format of the
  *                 split-f16 MFMA kernel, written once by the producer instead of being re-derived by
  *                 every consumer.  Channel offsets / counts / ld are multiples of 8 (a producer may
  *                 write a 4-channel half unit), bases 32-byte aligned. */
@@ -89,7 +89,14 @@ typedef struct vfml_conv_desc {
  * (a_hi*b_lo, a_lo*b_hi).  out[q][s] of a call with operands (A, B) and out[s][q] of the call with operands
  * (B, A) and this flag are then the same sequence of f32 additions, i.e. bit-identical - which makes a
  * correlation volume computed directly equal to the one obtained as another call's out_t. */
-enum { VFML_CONV_SWAP_CROSS = 1 };
+enum { VFML_CONV_SWAP_CROSS = 1,
+/* Fewer MFMAs per product, per call (the per-layer precision plan of the network, cfg.precision):
+ *   VFML_CONV_MFMA2  the weight operand as ONE f16 (its hi plane; hi is the round-to-nearest f16 of the weight, so the
+ *                    dropped a*w_lo term is an unbiased 2^-12 relative perturbation of each weight): a_hi w + a_lo w;
+ *   VFML_CONV_MFMA1  the activations as one f16 too: a_hi w - plain f16 inputs, f32 accumulate ("fp16" arithmetic).
+ * The lo halves that are not used are not fetched.  Where a tile shape / loader combination is not built for the
+ * reduced count the call runs with three MFMAs (never less accurate than asked). */
+       VFML_CONV_MFMA2 = 2, VFML_CONV_MFMA1 = 4 };
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
 

@@ -341,3 +341,62 @@ def test_two_clips_of_one_shape_through_one_engine(gpu):
         ref = mproc.compute_optical_flow_resident(clip, i)
         assert torch.equal(mb[k], ref), i
         assert not torch.equal(ma[k], ref)
+
+
+def test_bof_720p_seq9_fp16_config(gpu):
+    """BASELINE config 5 at its full size: BOF_things, seq_len 9, 1280x720, fp16.  The tri-frame network on the
+    centre triple of the 9-frame window, (a) in the fp32-grade arithmetic (f16x3) within the 1e-3 px tolerance of the
+    CPU oracle, (b) in 'f16' (plain f16 MFMA operands, one MFMA per product, f32 accumulate - the config's "fp16"):
+    EPE against the same fp32 oracle reported and bounded, (c) the job loop's batched evaluation (eight fields per
+    pass, tri_batch) bit-identical to one field per call at this size, in the f16 arithmetic."""
+    import contextlib
+    import io
+    import numpy as np
+    from oracle import mof_oracle as mo
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml import build_network, get_cfg
+    from vfml.synth import synthetic_clip
+    from vfml.weights import seeded_state_dict
+    H, W, T = 720, 1280, 9
+    frames = synthetic_clip(14, H, W)
+    cfg = get_cfg()
+    cfg.network = "BOFNet"
+    sd = seeded_state_dict(cfg, 0)
+    ocfg = mo.get_cfg()
+    ocfg.network = "BOFNet"
+    ora = mo.build_network(ocfg).eval()
+    ora.load_state_dict(sd)
+    i = 6                                                   # a field with a full window: frames 2..10, triple 5,6,7
+    win = np.stack(frames[i - T // 2:i + T // 2 + 1])
+    x = torch.from_numpy(win.astype(np.float32) / 255.0).permute(0, 3, 1, 2)[None]
+    ref, _ = ora(x, {})
+    ref = ref[0, ref.shape[1] // 2].permute(1, 2, 0)       # the reference's pick: the backward flow
+    got = {}
+    for prec in ("f16x3", "f16"):
+        c = get_cfg()
+        c.network, c.precision = "BOFNet", prec
+        net = build_network(c)
+        net.load_state_dict(sd)
+        net.cuda().eval()
+        with contextlib.redirect_stdout(io.StringIO()):
+            proc = VideoFlowProcessor("cuda", sequence_length=T, architecture="bof", dataset="things")
+        proc.core.model = net
+        clip = proc.upload_clip(frames)
+        f = proc.compute_optical_flow_resident(clip, i).clone()
+        e = (f.cpu() - ref).pow(2).sum(-1).sqrt()
+        got[prec] = (float(e.mean()), float(e.max()))
+        print(f"BOF 720p seq9 [{prec}]: mean EPE {got[prec][0]:.3e} px, max {got[prec][1]:.3e} px "
+              f"(|flow| mean {float(ref.abs().mean()):.3f} px)")
+        assert torch.isfinite(f).all()
+        if prec == "f16":
+            batched = [t.clone() for t in proc.compute_optical_flow_resident_batch(clip, list(range(14)))]
+            net.clear_feature_cache()
+            for k in (0, 3, 4, 6, 9, 10, 13):              # clip edges (repeated frames, one by one) and interior (batched)
+                assert torch.equal(batched[k], proc.compute_optical_flow_resident(clip, k)), k
+            assert torch.equal(batched[i], f)
+        del net, proc, clip
+        torch.cuda.empty_cache()
+    assert got["f16x3"][0] < EPE_TOL, got
+    # plain f16 operands through ~100 dependent layers and 12 iterations: well outside the fp32 tolerance by design;
+    # bounded here so that a broken kernel (not a rounding) fails
+    assert got["f16"][0] < 0.1 * max(1.0, float(ref.abs().mean())), got

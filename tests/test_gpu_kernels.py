@@ -689,3 +689,81 @@ def test_flow_lod_pyramid_bit_exact_vs_reference_fixture(gpu):
     cpu = LODGenerator.generate_lods(big.numpy(), 5)
     dev = LODGenerator.generate_lods(big.cuda(), 5)
     assert all(np.array_equal(a, b) for a, b in zip(cpu, dev))
+
+
+def _f16(t):
+    return t.half().double()
+
+
+@pytest.mark.parametrize("mfma", [2, 1])
+@pytest.mark.parametrize("cin,cout,kh,kw,stride,src16,cblock", [
+    (64, 192, 3, 3, 1, True, True),       # 128 x 192 / 192 x 128 tiles, uniform-step loader
+    (96, 128, 1, 5, 1, True, False),      # tap order: the general loader
+    (72, 100, 3, 3, 2, True, True),       # channel count not a multiple of 32, strided, ragged cout
+    (128, 64, 3, 3, 1, True, True),       # 128 x 64 tiles
+    (256, 4, 3, 3, 1, True, True),        # 128 x 32 tiles (flow head)
+    (64, 96, 3, 3, 2, False, False),      # f32 sources: the register-staged kernel
+    (4, 64, 7, 7, 2, False, False),       # encoder stem
+])
+def test_conv2d_reduced_mfma_counts_drop_exactly_the_lo_terms(gpu, mfma, cin, cout, kh, kw, stride, src16, cblock):
+    """VFML_CONV_MFMA2 / _MFMA1: the result equals a float64 convolution of (activations rounded to split rows |
+    to ONE f16) with (weights rounded to one f16, nearest) - i.e. exactly the a*w_lo (and a_lo*w) terms are gone, with
+    an unbiased rounding - and differs from the full-precision result by the f16 rounding of that operand."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(31 + mfma)
+    n, H, W = 2, 17, 22
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout, generator=g)
+    ph, pw = kh // 2, kw // 2
+    w = as_weight(pack_conv_weight(wt, cblock=cblock), cout, "f16x3", order=int(cblock))
+    # the kernel sees the weights times the power-of-two split scale, rounded to f16, then divides the scale out
+    wq = _f16(wt * w.scale) / w.scale
+    xq = _f16(x) if mfma == 1 else x.double()
+    emu = F.conv2d(xq, wq, b.double(), stride=stride, padding=(ph, pw)).float()
+    full = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=(ph, pw)).float()
+    ho, wo = emu.shape[-2:]
+    out = torch.full((n * ho * wo * cout,), float("nan"), device=gpu)
+    if src16:
+        src = torch.empty(n * H * W * cin, device=gpu)
+        hip.to_s16(nhwc(x), n * H * W, cin, cin, src, cin)
+    else:
+        src = nhwc(x)
+    hip.conv2d(src, cin, cin, n, H, W, w, b.cuda(), cout, kh, kw, out, cout, stride=stride, pad_h=ph, pad_w=pw,
+               in_fmt=hip.FMT_S16 if src16 else hip.FMT_F32, mfma=mfma)
+    got = from_nhwc(out, n, ho, wo, cout)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, emu) < CONV_TOL["f16x3"], rel_err(got, emu)
+    d = rel_err(got, full)
+    assert 5e-6 < d < 3e-3, d        # the f16 rounding is there, and is no more than that
+
+
+def test_gemm_form_reduced_mfma_counts(gpu):
+    """The persistent GEMM form (correlation volume) with two-plane weights at 2 and 1 MFMAs per product, incl. the
+    transposed second output, which at one MFMA per product is bit-identical to the direct reverse product."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(41)
+    P, S, D = 644, 1284, 256
+    f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
+    x16 = torch.empty(P * D, device=gpu)
+    hip.to_s16(f1.cuda().reshape(-1) * 16.0, P, D, D, x16, D)
+    y16 = torch.empty(S * D, device=gpu)
+    hip.to_s16(f2.cuda().reshape(-1) * 16.0, S, D, D, y16, D)
+    w2 = hip.SplitWeight(S, D, gpu).fill(f2.cuda().reshape(-1), scale=16.0)
+    w1 = hip.SplitWeight(P, D, gpu).fill(f1.cuda().reshape(-1), scale=16.0)
+    ld, ldt = (S + 31) // 32 * 32, (P + 31) // 32 * 32
+    for mfma in (2, 1):
+        out = torch.zeros(P * ld, device=gpu)
+        out_t = torch.zeros(S * ldt, device=gpu)
+        hip.conv2d(x16, D, D, 1, 1, P, w2, None, S, 1, 1, out, ld, out_scale=1.0 / 16.0, in_fmt=hip.FMT_S16, mfma=mfma,
+                   out_t=out_t, ld_out_t=ldt)
+        a = _f16(f1 * 16.0) / 16.0 if mfma == 1 else f1.double()
+        emu = (a @ (_f16(f2 * 16.0) / 16.0).t()).float()
+        got = out.view(P, ld)[:, :S].cpu()
+        assert rel_err(got, emu) < CONV_TOL["f16x3"]
+        assert torch.equal(out_t.view(S, ldt)[:, :P].cpu(), got.t())
+        if mfma == 1:
+            rev = torch.zeros(S * ldt, device=gpu)
+            hip.conv2d(y16, D, D, 1, 1, S, w1, None, P, 1, 1, rev, ldt, out_scale=1.0 / 16.0, in_fmt=hip.FMT_S16, mfma=1)
+            assert torch.equal(rev.view(S, ldt)[:, :P].cpu(), got.t())

@@ -25,6 +25,14 @@ class VideoFlowCore:
         self.variant = variant
         self.model = None
         self.cfg = None
+        # Arithmetic of the engine (vfml/cfg.py `precision`; an extension - the reference has no such switch, its
+        # submodule decides on autocast by itself): VFML_PRECISION = f16x3 | f16x2 | f16 | mixed | f32, and for
+        # 'mixed' VFML_MFMA_PLAN = JSON {layer prefix: 1|2|3}.  Unset: the engine's default (fp32-grade 'f16x3').
+        self.precision = os.environ.get("VFML_PRECISION") or None
+        self.mfma_plan = None
+        if os.environ.get("VFML_MFMA_PLAN"):
+            import json
+            self.mfma_plan = json.loads(os.environ["VFML_MFMA_PLAN"])
 
     # -- model ------------------------------------------------------------------------------
     def load_model(self):
@@ -38,6 +46,11 @@ class VideoFlowCore:
         # The reference passes the same cfg whatever the architecture (its comment at :100 expects the
         # network to be "detected from the weights"); here 'bof' selects the tri-frame network explicitly.
         cfg.network = "BOFNet" if self.architecture == "bof" else "MOFNetStack"
+        if self.precision:
+            cfg.precision = self.precision
+            if self.precision == "mixed":
+                from vfml.cfg import DEFAULT_MIXED_PLAN
+                cfg.mfma_plan = dict(self.mfma_plan if self.mfma_plan is not None else DEFAULT_MIXED_PLAN)
         if not os.path.exists(model_path):
             raise FileNotFoundError(f"VideoFlow model weights not found: {model_path}")
         self.cfg = cfg

@@ -18,6 +18,11 @@ class Cfg:
         return Cfg(**self.__dict__)
 
 
+# precision='mixed' without an explicit plan: MFMAs per product by layer-name prefix (vfml/network.py `_nm`), chosen
+# with tools/precision_plan.py under an end-point-error budget (DESIGN.md "Mixed plan"); 3 where nothing matches.
+DEFAULT_MIXED_PLAN = {}
+
+
 def get_cfg():
     return Cfg(
         model="",                 # checkpoint path, set by VideoFlowCore.load_model
@@ -34,6 +39,11 @@ def get_cfg():
         input_shift=-1.0,
         # arithmetic of the conv / correlation GEMMs:
         #   'f16x3' split-f16 on the f16 matrix cores (3 MFMAs per product, ~22 mantissa bits)
+        #   'f16x2' the same with every weight as one round-to-nearest f16 (2 MFMAs per product)
+        #   'f16'   plain f16 operands, f32 accumulate (1 MFMA per product): the "fp16" arithmetic of BASELINE
+        #           config 5 (BOF_things 720p fp16)
+        #   'mixed' per layer: mfma_plan {layer-name prefix: 1 | 2 | 3}, 3 where nothing matches
         #   'f32'   exact fp32 on the f32 matrix cores (v_mfma_f32_32x32x2_f32), 5.3x slower peak
         precision="f16x3",
+        mfma_plan=None,
     )

@@ -80,6 +80,7 @@ struct SplitArgs {
   int cswap;                    // VFML_CONV_SWAP_CROSS
   int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
   double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
+  int nm;                       // MFMAs per product: 3, 2 (weights as plain f16) or 1 (both operands plain f16)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -92,16 +93,7 @@ union U8 {
 // x (4 floats) -> hi/lo halves at element offset `at` (0 or 4) of the 8-wide units
 __device__ __forceinline__ void split4(const f32x4 x, U8& hi, U8& lo, int at) {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float a = x[2 * e], b = x[2 * e + 1];
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    // a - float(h): written as fma(float(h), -1, a) so that it selects v_fma_mix_f32 (f16 source
-    // operand, no separate v_cvt_f32_f16)
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -1.0f, a),
-                                                __builtin_fmaf((float)h[1], -1.0f, b));
-    hi.p[at / 2 + e] = __builtin_bit_cast(h16x2, h);
-    lo.p[at / 2 + e] = __builtin_bit_cast(h16x2, l);
-  }
+  for (int e = 0; e < 2; ++e) vfml_split2(x[2 * e], x[2 * e + 1], hi.p[at / 2 + e], lo.p[at / 2 + e]);
 }
 
 __device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float x0, float x1) {
@@ -236,7 +228,9 @@ __device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* s
 // IN16: the sources are already in the split-row format (VFML_FMT_S16: per pixel and 8-channel group
 // 16 B of hi halves then 16 B of lo halves), so the two 16-byte loads of a unit ARE its hi and lo
 // LDS images and no conversion happens in the loop.
-template <int BN, int WM, int WN, bool BIGC, bool IN16>
+// NM: MFMAs per product (SplitArgs::nm): 3 = hi*hi + hi*lo + lo*hi; 2 = the weight operand as plain f16
+// (hi*hi + lo*hi); 1 = both operands plain f16 (hi*hi).
+template <int BN, int WM, int WN, bool BIGC, bool IN16, int NM = 3>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const SplitArgs a) {
   constexpr int NT = WM * WN * 64;  // threads: 256 (4 waves) or 512 (8 waves, finer MFMA interleave per SIMD)
   constexpr int LR = NT / 4;        // rows covered by one pass of the loader (4 k-groups per row)
@@ -433,20 +427,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = sAh[oa + (2 * ks + half) * RSA + i * 32];
-        al[i] = sAl[oa + (2 * ks + half) * RSA + i * 32];
+        if constexpr (NM >= 2) al[i] = sAl[oa + (2 * ks + half) * RSA + i * 32];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = sBh[ob + (2 * ks + half) * RSB + j * 32];
-        bl[j] = sBl[ob + (2 * ks + half) * RSB + j * 32];
+        if constexpr (NM >= 3) bl[j] = sBl[ob + (2 * ks + half) * RSB + j * 32];
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (NM >= 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (NM >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
   };
@@ -558,10 +552,13 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 // FASTK: the uniform-step loader (SplitArgs::fastk) as a compile-time choice - with both loaders in one
 // body hipcc stops unrolling the MFMA loops of the larger tiles and the accumulators go to scratch.
 // CSWAP: VFML_CONV_SWAP_CROSS as a compile-time choice (GEMM form only; a runtime branch in the MFMA loop spills).
-// BHI: the weight operand is one plain f16 plane (hi only, SplitArgs::bhi): its lo slots are never fetched (those
-// lanes of a weight piece carry an out-of-range offset) nor read, and a product is two MFMAs (a_hi b + a_lo b).
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, bool BHI = false>
+// NM: MFMAs per product (SplitArgs::nm).  2: the weight operand is taken as plain f16 - its lo slots are never
+// fetched (those lanes of a weight piece carry an out-of-range offset) nor read, a product is a_hi b + a_lo b; the
+// operand may then be ONE f16 plane without a lo plane at all (SplitArgs::bhi).  1: the activation operand as
+// plain f16 too (its lo slots are not fetched either), one MFMA per product.
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
+  constexpr bool BHI = NM < 3;
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
   constexpr int AP = TBM / (8 * NW), BP = TBN / (8 * NW);  // 1-KiB pieces (8 rows x 128 B) per wave per K step
@@ -668,13 +665,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       for (int j = 0; j < AP; ++j) {
         rp0[j] += a.abias + kg * 32 + hl * 16;
         tapok[j] = ~tapok[j];
+        if (NM == 1 && hl) rp0[j] |= (int)0x80000000;      // lo slots of the activations: never fetched
       }
       scb = sky = skx = 0;
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int col = n0 + 8 * NW * j + lrow;
-      colbase[j] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : (BHI ? 0x7ffffff0 : 0x40000000);
+      colbase[j] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : (a.bhi ? 0x7ffffff0 : 0x40000000);
     }
     if (a.tilebase) {
       // GEMM rows of a source that can exceed what one descriptor spans: base it at this tile's first row
@@ -727,7 +725,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
     const int tap = kok ? kky * a.kw + kkx : 63;   // bit 63 is never set (kh*kw < 64, host check)
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
-      const bool ok = (tapok[j] >> tap) & 1ull;
+      const bool ok = ((tapok[j] >> tap) & 1ull) && !(NM == 1 && hl);
       va[j] = ok ? (s1 ? rp1[j] : rp0[j]) + tapoff : OOB;
     }
     if (a.korder) {          // next tap of the same 32 channels; after the last tap the next 32 channels
@@ -787,7 +785,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64)) + i * 4096);
-        al[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64 + 16)) + i * 4096);
+        if constexpr (NM >= 2) al[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64 + 16)) + i * 4096);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -806,7 +804,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #ifndef VFML_EXPERIMENT_2MFMA     // timing / accuracy experiment: second operand (weights) as plain f16
             if constexpr (!BHI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #endif
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            if constexpr (NM >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
           }
 #ifndef VFML_ISSUE_GROUPS
 #define VFML_ISSUE_GROUPS (TM * TN)      // the first half of the step: the second half covers the pieces' L2 latency
@@ -993,7 +991,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, bool BHI = false>
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
   constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
@@ -1004,7 +1002,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   a.ntiles = (a.cout + TBN - 1) / TBN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, BHI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1016,32 +1014,45 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.mtiles * a.ntiles;
   const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
   const int grid = (int)(PERSIST && total > slots ? slots : total);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, BHI>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
 template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
   if (a.direct) {   // (128 x 128: the one persistent tile shape that does not spill)
-    if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk)
-    if (a.bhi) return launch_dma_k<2, 2, 2, 2, true, true, false, true>(a, s);  // (host: bhi implies fastk, no cswap)
+    if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
+    if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
+    if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
+    a.nm = 3;       // (the general-loader GEMM form exists at full precision only: never less accurate than asked)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
   }
-  if constexpr (WM * WN == 4 && TM * TN >= 2) {   // the shapes the dispatcher picks by itself
-    if (a.fastk) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
+  if constexpr (WM * WN == 4) {   // the shapes the dispatcher picks by itself
+    if constexpr (TM * TN >= 2) {
+      if (a.fastk) {
+        if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2>(a, s);
+        if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, true, false, 1>(a, s);
+        return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
+      }
+    }
+    a.fastk = 0; a.abias = 0;
+    if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, false, false, 2>(a, s);
+    if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, false, false, 1>(a, s);
+    return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
   }
   a.fastk = 0; a.abias = 0;
+  a.nm = 3;         // (8-wave experiment shapes: full precision only)
   return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
 }
 
-template <int BN, int WM, int WN, bool BIGC, bool IN16>
-int launch(const SplitArgs& a, hipStream_t s) {
+template <int BN, int WM, int WN, bool BIGC, bool IN16, int NM>
+int launch_nm(const SplitArgs& a, hipStream_t s) {
   constexpr size_t stage = 2 * 2 * (KG * (BM + 2) + KG * (BN + 2)) * 16;
   constexpr size_t ctile = (size_t)BM * (BN + 4) * 4;
   constexpr size_t lds = stage > ctile ? stage : ctile;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<BN, WM, WN, BIGC, IN16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<BN, WM, WN, BIGC, IN16, NM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1049,8 +1060,15 @@ int launch(const SplitArgs& a, hipStream_t s) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_split_kernel<BN, WM, WN, BIGC, IN16>), dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_split_kernel<BN, WM, WN, BIGC, IN16, NM>), dim3(a.mtiles * a.ntiles), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
+}
+
+template <int BN, int WM, int WN, bool BIGC, bool IN16>
+int launch(const SplitArgs& a, hipStream_t s) {
+  if (a.nm == 1) return launch_nm<BN, WM, WN, BIGC, IN16, 1>(a, s);
+  if (a.nm == 2) return launch_nm<BN, WM, WN, BIGC, IN16, 2>(a, s);
+  return launch_nm<BN, WM, WN, BIGC, IN16, 3>(a, s);
 }
 
 // f32 [rows][k] (row stride ld) * scale -> hi/lo f16 planes [rows][kp], zero padded to kp
@@ -1062,10 +1080,10 @@ __global__ void split_f16_kernel(const float* __restrict__ src, int64_t rows, in
     const int c = (int)(i - rrow * (kp / 2)) * 2;
     const float a = c < k ? src[rrow * ld + c] * scale : 0.f;
     const float b = c + 1 < k ? src[rrow * ld + c + 1] * scale : 0.f;
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
-    *reinterpret_cast<fp16x2*>(hi + rrow * kp + c) = h;
-    *reinterpret_cast<fp16x2*>(lo + rrow * kp + c) = l;
+    h16x2 h, l;
+    vfml_split2(a, b, h, l);
+    *reinterpret_cast<h16x2*>(hi + rrow * kp + c) = h;
+    *reinterpret_cast<h16x2*>(lo + rrow * kp + c) = l;
   }
 }
 
@@ -1103,10 +1121,10 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
     const int col = c0 + cc, k = r0 + kk;
     if (col >= c || k >= kp) continue;
     const float a = tile[kk][cc], b = tile[kk + 1][cc];
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
-    *reinterpret_cast<fp16x2*>(hi + (int64_t)col * kp + k) = h;
-    *reinterpret_cast<fp16x2*>(lo + (int64_t)col * kp + k) = l;
+    h16x2 h, l;
+    vfml_split2(a, b, h, l);
+    *reinterpret_cast<h16x2*>(hi + (int64_t)col * kp + k) = h;
+    *reinterpret_cast<h16x2*>(lo + (int64_t)col * kp + k) = l;
   }
 }
 
@@ -1234,11 +1252,11 @@ __global__ __launch_bounds__(256) void transpose_to_s16_kernel(const float* __re
     const int col = c0 + cc, k = r0 + kk;
     if (col >= c || 2 * (int64_t)k >= ld_dst_h) continue;       // (rows past `rows` inside the row stride: zeros)
     const float a = tile[kk][cc], b = tile[kk + 1][cc];
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    h16x2 h, l;
+    vfml_split2(a, b, h, l);
     _Float16* u = dst + (int64_t)col * ld_dst_h + (k >> 3) * 16 + (k & 7);   // unit k/8: 8 hi halves, then 8 lo halves
-    *reinterpret_cast<fp16x2*>(u) = h;
-    *reinterpret_cast<fp16x2*>(u + 8) = l;
+    *reinterpret_cast<h16x2*>(u) = h;
+    *reinterpret_cast<h16x2*>(u + 8) = l;
   }
 }
 
@@ -1361,9 +1379,12 @@ extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, flo
 extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
                                  int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
-  VFML_REQUIRE((d->flags & ~VFML_CONV_SWAP_CROSS) == 0, "vfml_conv2d_split: unknown flag bits");
-  VFML_REQUIRE(in_fmt == VFML_FMT_S16 || (d->flags == 0 && d->out_t == nullptr),
-               "vfml_conv2d_split: out_t / flags need split-row sources");
+  VFML_REQUIRE((d->flags & ~(VFML_CONV_SWAP_CROSS | VFML_CONV_MFMA2 | VFML_CONV_MFMA1)) == 0, "vfml_conv2d_split: unknown flag bits");
+  VFML_REQUIRE(!((d->flags & VFML_CONV_MFMA2) && (d->flags & VFML_CONV_MFMA1)) &&
+               !((d->flags & VFML_CONV_SWAP_CROSS) && (d->flags & (VFML_CONV_MFMA2 | VFML_CONV_MFMA1))),
+               "vfml_conv2d_split: VFML_CONV_MFMA2 / _MFMA1 / _SWAP_CROSS exclude one another");
+  VFML_REQUIRE(in_fmt == VFML_FMT_S16 || ((d->flags & VFML_CONV_SWAP_CROSS) == 0 && d->out_t == nullptr),
+               "vfml_conv2d_split: out_t / VFML_CONV_SWAP_CROSS need split-row sources");
   if (d->stats_part) {
     const int64_t hw_out = (int64_t)((d->h + 2 * d->pad_h - d->kh) / d->stride + 1) * ((d->w + 2 * d->pad_w - d->kw) / d->stride + 1);
     VFML_REQUIRE(in_fmt == VFML_FMT_F32 && out_fmt == VFML_FMT_F32 && d->epilogue == VFML_EPI_NONE && !d->addend &&
@@ -1437,6 +1458,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   SplitArgs a;
   a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0; a.bhi = 0;
   a.stats_part = d->stats_part;
+  a.nm = (d->flags & VFML_CONV_MFMA1) ? 1 : ((d->flags & VFML_CONV_MFMA2) || bhi) ? 2 : 3;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;

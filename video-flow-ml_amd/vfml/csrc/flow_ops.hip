@@ -88,10 +88,9 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
     const float v = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[side] * (wx0 * fy) + p[side + 1] * (fx * fy);
     if (a.out16) {
-      typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
-      const fp16x2_ hh = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
-      const fp16x2_ ll = __builtin_amdgcn_cvt_pkrtz(v - (float)hh[0], 0.f);
-      __fp16* u = reinterpret_cast<__fp16*>(o + (c & ~7));
+      vfml_h16x2 hh, ll;
+      vfml_split2(v, 0.f, hh, ll);
+      _Float16* u = reinterpret_cast<_Float16*>(o + (c & ~7));
       u[c & 7] = hh[0];
       u[8 + (c & 7)] = ll[0];
     } else {
@@ -187,10 +186,9 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
       }
     }
     if (OUT16) {
-      typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
-      const fp16x2_ h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-      const fp16x2_ l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
-      const fp16x2_ l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+      vfml_h16x2 h0, h1, l0, l1;
+      vfml_split2(v[0], v[1], h0, l0);
+      vfml_split2(v[2], v[3], h1, l1);
       // quad c4 of unit c4/2: hi halves at byte 8*(c4&1) of the 32-byte unit, lo halves 16 bytes further
       char* u = reinterpret_cast<char*>(o + (c4 >> 1) * 8) + 8 * (c4 & 1);
       uint2 hv, lv;
@@ -236,10 +234,10 @@ __global__ void coords_update_kernel(f32x4* __restrict__ coords, const f32x4* __
     if (fa) *reinterpret_cast<f32x4*>(fa + p * lda) = f;
     if (fb) {
       if (b16) {   // second quad of a split-row unit: hi halves at +0 (8 B), lo halves 16 B further
-        typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
-        const fp16x2_ h0 = __builtin_amdgcn_cvt_pkrtz(f[0], f[1]), h1 = __builtin_amdgcn_cvt_pkrtz(f[2], f[3]);
-        const fp16x2_ l0 = __builtin_amdgcn_cvt_pkrtz(f[0] - (float)h0[0], f[1] - (float)h0[1]);
-        const fp16x2_ l1 = __builtin_amdgcn_cvt_pkrtz(f[2] - (float)h1[0], f[3] - (float)h1[1]);
+        typedef vfml_h16x2 fp16x2_;
+        fp16x2_ h0, h1, l0, l1;
+        vfml_split2(f[0], f[1], h0, l0);
+        vfml_split2(f[2], f[3], h1, l1);
         // fb points at channel 4 of the unit = byte 16 of it in f32 addressing; the quad slot of the
         // hi halves is byte 8 of the unit
         char* u = reinterpret_cast<char*>(fb + p * ldb) - 16;

@@ -8,6 +8,24 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef _Float16 vfml_h16x2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> hi = round-to-nearest f16 pair (v_cvt_pk_f16_f32), lo = f16(x - hi): the two halves of a split-row
+// channel (VFML_FMT_S16).  Nearest, not toward zero: a consumer that drops the lo half of an operand
+// (VFML_CONV_MFMA2 / _MFMA1) then sees an UNBIASED f16 rounding of it (2^-12 relative), and |lo| <= half an ulp of
+// hi.  The empty asm keeps hipcc from redoing the two conversions element by element for the subtraction.
+__device__ __forceinline__ void vfml_split2(float a, float b, vfml_h16x2& h, vfml_h16x2& l) {
+  vfml_h16x2 hh = {(_Float16)a, (_Float16)b};
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned hp = __builtin_bit_cast(unsigned, hh);
+  asm volatile("" : "+v"(hp));
+  hh = __builtin_bit_cast(vfml_h16x2, hp);
+#endif
+  h = hh;
+  const vfml_h16x2 ll = {(_Float16)(a - (float)hh[0]), (_Float16)(b - (float)hh[1])};
+  l = ll;
+}
+
 void vfml_set_error(const char* fmt, ...);
 
 #define VFML_REQUIRE(cond, ...)            \

@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 KORDER_TAP, KORDER_CBLOCK = 0, 1   # K-axis order of split weight planes (include/vfml.h)
-CONV_SWAP_CROSS = 1                 # vfml_conv_desc.flags
+CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1 = 1, 2, 4   # vfml_conv_desc.flags
 
 
 class ConvDesc(ctypes.Structure):
@@ -103,7 +103,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 14:
+    if L.vfml_abi_version() != 15:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -188,7 +188,7 @@ def profile_end():
 
 
 def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False,
-                 cswap=False, bhi=False):
+                 cswap=False, nm=3):
     """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
     the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
     split kernel for cout > 64 is not modelled)."""
@@ -199,12 +199,13 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
     if dma:     # split-f16, LDS-DMA staged
         fk = "true" if fastk else "false"       # uniform-step loader (SplitArgs::fastk)
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
-            return (f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, "
-                    f"{'true' if bhi else 'false'}>")   # persistent GEMM form
+            if not fastk:
+                nm = 3
+            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}>"   # persistent GEMM form
         if cout <= 32:
-            return "conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, false>"
+            return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}>"
         if cout <= 64:
-            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, false>"
+            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, {nm}>"
         def cost(tbm, tbn, mf, eff):
             tiles = -(-m // tbm) * -(-cout // tbn)
             return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
@@ -215,9 +216,9 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         for c, name in cands[1:]:
             if c < best:
                 best, t = c, name
-        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, false>"
+        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, {nm}>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
-    return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}>"
+    return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}, {nm}>"
 
 
 class SplitWeight:
@@ -261,9 +262,10 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
-           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None):
+           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
-    (channel slices of wider NHWC buffers)."""
+    (channel slices of wider NHWC buffers).  mfma: MFMAs per product of the split-f16 kernel (3; 2 = weights as
+    plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA1)."""
     d = ConvDesc()
     d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
     d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
@@ -278,7 +280,9 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
     d.addend, d.ld_addend = (_ptr(_dev(addend), addend_off) if addend is not None else None), ld_addend
     d.out_t, d.ld_out_t = (_ptr(_dev(out_t), out_t_off) if out_t is not None else None), ld_out_t
-    d.flags = CONV_SWAP_CROSS if swap_cross else 0
+    if mfma not in (1, 2, 3) or (swap_cross and mfma != 3):
+        raise ValueError(f"mfma={mfma}: 1, 2 or 3 (3 with swap_cross)")
+    d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, 1: CONV_MFMA1}[mfma]
     d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
@@ -310,7 +314,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
              and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
                                   weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
-                                  is_split and weight.lo is None),
+                                  min(mfma, 2) if (is_split and weight.lo is None) else mfma),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)

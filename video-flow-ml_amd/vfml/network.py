@@ -83,7 +83,7 @@ class MOFNetHIP(_Holder):
 
     def _pack(self, device):
         """Repack every conv weight into the kernels' [cout][kh][kw][cin] order (once per load)."""
-        split = self._precision() == "f16x3"
+        split = self._split()
         key = (str(device), split, tuple(p._version for p in self.parameters()),
                tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is not None and self._packed_key == key:
@@ -150,11 +150,47 @@ class MOFNetHIP(_Holder):
         self._feat_cache.clear()
         return P
 
+    PRECISIONS = ("f16x3", "f16x2", "f16", "mixed", "f32")
+
     def _precision(self):
         p = getattr(self.cfg, "precision", "f16x3")
-        if p not in ("f16x3", "f32"):
-            raise ValueError(f"cfg.precision must be 'f16x3' or 'f32', got {p!r}")
+        if p not in self.PRECISIONS:
+            raise ValueError(f"cfg.precision must be one of {self.PRECISIONS}, got {p!r}")
         return p
+
+    def _split(self):
+        """Every arithmetic but 'f32' runs the split-f16 kernels on split-row activations; they differ in the
+        number of MFMAs a layer spends per product (`_nm`)."""
+        return self._precision() != "f32"
+
+    def _nm(self, layer):
+        """MFMAs per product for `layer` (a conv_spec name, '.iter' / '.ctx' for the two parts of a GRU gate
+        convolution, or 'corr' for the correlation GEMMs): 3 = fp32-grade split product, 2 = weights as plain f16,
+        1 = both operands plain f16.  'f16x3' / 'f16x2' / 'f16' = 3 / 2 / 1 everywhere; 'mixed' = cfg.mfma_plan,
+        {name prefix: count}, longest prefix wins, 3 where nothing matches."""
+        p = self._precision()
+        if p == "f16x3":
+            nm = 3
+        elif p == "f16x2":
+            nm = 2
+        elif p == "f16":
+            nm = 1
+        else:
+            plan = getattr(self.cfg, "mfma_plan", None) or {}
+            best, nm = -1, 3
+            for prefix, n in plan.items():
+                if layer.startswith(prefix) and len(prefix) > best:
+                    best, nm = len(prefix), int(n)
+            if nm not in (1, 2, 3):
+                raise ValueError(f"cfg.mfma_plan[{layer!r}] = {nm}: 1, 2 or 3")
+        if layer == "corr" and nm == 2:
+            nm = 3       # a volume and its transpose must stay the same numbers: the symmetric counts only
+        return nm
+
+    def _plan_key(self):
+        """The arithmetic as part of a cached frame's identity."""
+        p = self._precision()
+        return (p, tuple(sorted((getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, name, numel, device, dtype=torch.float32, zero=False):
@@ -188,7 +224,7 @@ class MOFNetHIP(_Holder):
 
         # split-f16 path: the convolution leaves per-tile sums behind (its tile is in LDS anyway) and only the fold
         # remains; row tiles of 128 pixels must not straddle frames
-        split_prec = self._precision() == "f16x3"
+        split_prec = self._split()
         part_len = n * ((h2 * w2 + 127) // 128) * 128 * 2          # largest layer: half resolution
         parts = self._buf("enc_part", 3 * part_len, dev, torch.float64) if split_prec else None
 
@@ -197,15 +233,17 @@ class MOFNetHIP(_Holder):
 
         def conv_stats(src, c, hh_, ww_, name, planes, dst, slot, k, stride=1, pad=0):
             wgt, b = P[name]
+            nm = self._nm(name) if split_prec else 3
             ho_, wo_ = (hh_ + 2 * pad - k) // stride + 1, (ww_ + 2 * pad - k) // stride + 1
             hw = ho_ * wo_
             if not fused(hw):
-                hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad)
+                hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
+                           mfma=nm)
                 return stats_of(dst, hw, planes, slot)
             chunks = (hw + 127) // 128
             part = parts[slot * part_len:]
             hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
-                       stats_part=part)
+                       stats_part=part, mfma=nm)
             s = st[slot * n * 128 * 2:]
             hip.instnorm_finalize(part, n, chunks, planes, hw, s)
             return s
@@ -233,7 +271,7 @@ class MOFNetHIP(_Holder):
                 ch, hh, ww = planes, ho, wo
         wgt, b = P[f"{prefix}.conv2"]
         hip.conv2d(cur, 128, 128, n, hh, ww, wgt, b, 256, 1, 1, out, ldo, out_off=out_off, epilogue=epilogue,
-                   split=split, out_fmt=out_fmt)
+                   split=split, out_fmt=out_fmt, mfma=self._nm(f"{prefix}.conv2") if split_prec else 3)
         return hh, ww
 
     # ------------------------------------------------------------------ forward
@@ -320,7 +358,7 @@ class MOFNetHIP(_Holder):
         """Feature map + target pyramid of frames `sel` of the window.
         Returns {j: (fmap [Pn*256] f32, [target operand per level])}."""
         D = self.cfg.feat_dim
-        split = self._precision() == "f16x3"
+        split = self._split()
         out, todo = {}, []
         for j in sel:
             ent = self._cache_get("f", keys[j]) if keys is not None else None
@@ -376,7 +414,7 @@ class MOFNetHIP(_Holder):
             hip.frames_to_nhwc4(take_frames(src, todo).contiguous(), m, H, W,
                                 float(self.cfg.input_scale), float(self.cfg.input_shift), frames)
             ctx = torch.empty(m * Pn * 256, device=dev)
-            AF = hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32
+            AF = hip.FMT_S16 if self._split() else hip.FMT_F32
             self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim, out_fmt=AF)
             h8, w8 = H // 8, W // 8
             for i, j in enumerate(todo):
@@ -388,7 +426,8 @@ class MOFNetHIP(_Holder):
                         wgt, b = P[f"update_block.gru.conv{g}{k}.ctx"]
                         a = torch.empty(Pn * co, device=dev)
                         hip.conv2d(cx, 128, 256, 1, h8, w8, wgt, b, co, kh, kw, a, co, in0_off=128,
-                                   pad_h=kh // 2, pad_w=kw // 2, in_fmt=AF)
+                                   pad_h=kh // 2, pad_w=kw // 2, in_fmt=AF,
+                                   mfma=self._nm(f"update_block.gru.conv{g}{k}.ctx") if self._split() else 3)
                         add[g + k] = a
                 out[j] = (cx, add)
                 if keys is not None:
@@ -417,7 +456,7 @@ class MOFNetHIP(_Holder):
         P = self._pack(dev)
         win = (2 * R + 1) ** 2
         cor = L * win
-        AF = hip.FMT_S16 if self._precision() == "f16x3" else hip.FMT_F32   # update-block activations
+        AF = hip.FMT_S16 if self._split() else hip.FMT_F32   # update-block activations
         cor_p = (cor + 7) // 8 * 8 if AF == hip.FMT_S16 else (cor + 3) // 4 * 4   # per-direction channel block
 
         with torch.cuda.device(dev):
@@ -429,7 +468,7 @@ class MOFNetHIP(_Holder):
             ldl = [(s + 31) // 32 * 32 for s in Sl]
             keys = None
             if frame_keys is not None:   # geometry and arithmetic are part of a cached frame's identity
-                keys = [(k, H, W, L, self._precision(), self._packed_serial) for k in frame_keys]
+                keys = [(k, H, W, L, self._plan_key(), self._packed_serial) for k in frame_keys]
 
             # K1 + K2: feature maps and pooled target pyramids, per frame (cached across windows)
             feats = self._frame_features(src, list(range(N)), keys, H, W, P, dev, L, hl, wl, Sl)
@@ -470,14 +509,18 @@ class MOFNetHIP(_Holder):
                         if dual:
                             rev = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=lim)
                             self._cache_put("p", rk, rev, limit=lim)
+                        cnm = self._nm("corr") if self._split() else 3
                         for l in range(L):
+                            # (one MFMA per product is symmetric in its operands: no swapped cross terms to order)
                             hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[l],
-                                       ldl[l], out_scale=scale, in_fmt=AF, swap_cross=(d == "b" and l == 0 and gemm_form),
-                                       out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0)
+                                       ldl[l], out_scale=scale, in_fmt=AF,
+                                       swap_cross=(d == "b" and l == 0 and gemm_form and cnm == 3),
+                                       out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0,
+                                       mfma=cnm)
                         if dual:
                             for l in range(1, L):
                                 hip.conv2d(feats[tgt][0], D, D, 1, 1, Pn, feats[c][1][l], None, Sl[l], 1, 1, rev[l],
-                                           ldl[l], out_scale=scale, in_fmt=AF)
+                                           ldl[l], out_scale=scale, in_fmt=AF, mfma=cnm)
                         if os.environ.get("VFML_EXPERIMENT_CORR16"):   # precision experiment: the volume rounded to f16
                             for t in pyr + (rev or []):
                                 t.copy_(t.half().float())
@@ -511,6 +554,7 @@ class MOFNetHIP(_Holder):
             hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
                               fmt_b=AF)
             ub = "update_block"
+            mf = self._nm if self._split() else (lambda layer: 3)     # MFMAs per product of a layer (cfg.precision)
             for it in range(cfg.decoder_depth):
                 # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
                 # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
@@ -525,29 +569,29 @@ class MOFNetHIP(_Holder):
                 # motion encoder
                 wgt, b = P[f"{ub}.encoder.convc1"]
                 hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
-                           in_fmt=AF, out_fmt=AF)
+                           in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc1"))
                 wgt, b = P[f"{ub}.encoder.convc2"]
                 hip.conv2d(c1, 256, 256, nm, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
-                           in_fmt=AF, out_fmt=AF)
+                           in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc2"))
                 wgt, b = P[f"{ub}.encoder.convf1"]
                 hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
-                           out_fmt=AF)
+                           out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
                 wgt, b = P[f"{ub}.encoder.convf2"]
                 hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf2"))
                 wgt, b = P[f"{ub}.encoder.conv"]
                 hip.conv2d(cf, 256, 256, nm, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.conv"))
                 # temporal stack fusion: 3x1 conv along the frame axis of the motion features
                 wgt, b = P[f"{ub}.tprop"]
                 if self.tri_frame:     # every centre frame is its own problem: its neighbours are the zero padding
                     hip.conv2d(G, 128, GLD, M, 1, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
-                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.tprop"))
                 else:
                     # (on the first nm frames: row nm-1 of a shortened stack sees zero padding where its lower
                     # neighbour was - that row is not among the ng < nm the GRU reads)
                     hip.conv2d(G, 128, GLD, 1, nm, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
-                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.tprop"))
                 # SepConvGRU, horizontal then vertical
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
@@ -555,20 +599,22 @@ class MOFNetHIP(_Holder):
                     hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
                                in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
-                               addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                               addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF,
+                               mfma=mf(f"{ub}.gru.convzr{k}.iter"))
                     wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
                     # h = (1 - z) h + z tanh(conv([r*h | motion | temporal]) + context part), in place
                     hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
                                in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
                                aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
-                               in_fmt=AF, out_fmt=AF, aux_fmt=AF)
+                               in_fmt=AF, out_fmt=AF, aux_fmt=AF, mfma=mf(f"{ub}.gru.convq{k}.iter"))
                 # flow head
                 wgt, b = P[f"{ub}.flow_head.conv1"]
                 hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.flow_head.conv1"))
                 wgt, b = P[f"{ub}.flow_head.conv2"]
-                hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF)
+                hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF,
+                           mfma=mf(f"{ub}.flow_head.conv2"))
                 hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
                                   flow_b_off=MF + 124, fmt_b=AF)
 
@@ -578,9 +624,10 @@ class MOFNetHIP(_Holder):
             mask = self._buf("mask", MP * 1152, dev)
             wgt, b = P[f"{ub}.mask.0"]
             hip.conv2d(G, 128, GLD, no, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                       epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF)
+                       epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.mask.0"))
             wgt, b = P[f"{ub}.mask.2"]
-            hip.conv2d(fh, 256, 256, no, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF)
+            hip.conv2d(fh, 256, 256, no, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF,
+                       mfma=mf(f"{ub}.mask.2"))
             if pick_only and not self.tri_frame:
                 up = torch.empty(1, H, W, 2, device=dev, dtype=torch.float32)
                 hip.convex_upsample(coords1, 0, 2, mask, 576, 1152, h, w, up.view(-1))

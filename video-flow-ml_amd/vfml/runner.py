@@ -78,6 +78,11 @@ class ClipFeeder:
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # earlier readers of the old frames
 
+    def skip_to(self, frame):
+        """Frames before `frame` will not be needed (a rank whose shard starts later in the clip): they are never
+        uploaded.  Only moves forward."""
+        self.next = max(self.next, min(frame, len(self.frames)))
+
     def ensure(self, upto):
         upto = min(upto, len(self.frames) - 1)
         if upto < self.next:
@@ -127,8 +132,27 @@ def default_chunk(slot_floats, n_items, world):
     return int(max(1, min(2, (128 << 20) // max(1, 4 * slot_floats), n_items)))
 
 
+_BUFFERS = {}
+
+
+def _buffer(kind, shape, device, pinned=False):
+    """Staging buffers are kept across jobs of one geometry (pinned host allocations cost ~0.2 ms per MB)."""
+    key = (kind, tuple(shape), str(device), pinned)
+    t = _BUFFERS.get(key)
+    if t is None:
+        t = torch.empty(shape, dtype=torch.float32, device="cpu" if pinned else device)
+        if pinned:
+            t = t.pin_memory()
+        _BUFFERS[key] = t
+    return t
+
+
+def release_buffers():
+    _BUFFERS.clear()
+
+
 def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None, on_field=None,
-                collect=True, num_lods=0, chunk=None, feeder=None):
+                collect=True, num_lods=0, chunk=None, feeder=None, prepare_only=False):
     """Compute the flow field of every frame in `frame_indices` of the device-resident uint8 clip [F,H,W,3]
     (`clip` may be None when a ClipFeeder is given: its clip is used and fed as the job advances).
     Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2] (None with collect=False, when the
@@ -136,7 +160,8 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     `on_field(k, field, lods)` is called on rank 0 for every finished frame as soon as it (in tile mode: its last
     tile) has reached host memory, k = position in `frame_indices`; `field` is a host array the callee may keep;
     `lods` is None or, with num_lods > 1 (whole frames only), the reference's LOD pyramid [field, lod1, ...] reduced
-    on the GPU that computed the field (vfml_flow_lod, bit-identical to the reference's loop)."""
+    on the GPU that computed the field (vfml_flow_lod, bit-identical to the reference's loop).
+    prepare_only: allocate the job's staging buffers (kept for later jobs of the same geometry) and return."""
     frame_indices = list(frame_indices)
     if feeder is not None:
         clip = feeder.clip
@@ -155,21 +180,24 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     K = chunk or default_chunk(slot, max(counts) if counts else 1, world)
     n_chunks = -(-max(counts) // K) if counts and max(counts) > 0 else 0
     dev = clip.device
-    send = [torch.empty((K, slot), dtype=torch.float32, device=dev) for _ in range(min(2, n_chunks))]
+    nb = min(2, n_chunks)
+    send = [_buffer(f"send{i}", (K, slot), dev) for i in range(nb)]
     recv = host = None
     if rank == 0 and n_chunks:
         if world > 1:
-            recv = [[torch.empty((K, slot), dtype=torch.float32, device=dev) for _ in range(world)]
-                    for _ in range(min(2, n_chunks))]
-        shape = (world, K, slot)
-        host = [torch.empty(shape, dtype=torch.float32).pin_memory() if on_gpu else torch.empty(shape, dtype=torch.float32)
-                for _ in range(min(2, n_chunks))]
+            recv = [[_buffer(f"recv{i}.{r}", (K, slot), dev) for r in range(world)] for i in range(nb)]
+        host = [_buffer(f"host{i}", (world, K, slot), dev, pinned=on_gpu) for i in range(nb)]
+    if prepare_only:
+        return None
     side = torch.cuda.Stream(device=dev) if on_gpu and rank == 0 else None
     seq = getattr(proc, "sequence_length", 1)
 
     out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32) if (rank == 0 and collect) else None
     slot_of = {f: k for k, f in enumerate(frame_indices)}
     partial, left = {}, {}                                  # tile mode without `collect`: frames being assembled
+
+    if feeder is not None and mine:
+        feeder.skip_to(min(f for f, _ in mine) - seq)       # (a window reaches at most seq - 1 frames back)
 
     def feed(frame):
         if feeder is not None:
