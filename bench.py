@@ -261,7 +261,7 @@ def main():
         name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         split = "split" in name or "dma" in name      # the split-f16 kernels; the last template argument = MFMAs per product
-        nm = int(name.rstrip(">").split(",")[-1]) if split else 1
+        nm = {4: 2}.get(int(name.rstrip(">").split(",")[-1]), int(name.rstrip(">").split(",")[-1])) if split else 1
         peak = F16_MATRIX_PEAK_TFLOPS / nm if split else F32_MATRIX_PEAK_TFLOPS
         traffic, traffic_note = hbm_traffic_from_profiles(name, args.workload)
         result["roofline"] = {

@@ -93,10 +93,14 @@ enum { VFML_CONV_SWAP_CROSS = 1,
 /* Fewer MFMAs per product, per call (the per-layer precision plan of the network, cfg.precision):
  *   VFML_CONV_MFMA2  the weight operand as ONE f16 (its hi plane; hi is the round-to-nearest f16 of the weight, so the
  *                    dropped a*w_lo term is an unbiased 2^-12 relative perturbation of each weight): a_hi w + a_lo w;
- *   VFML_CONV_MFMA1  the activations as one f16 too: a_hi w - plain f16 inputs, f32 accumulate ("fp16" arithmetic).
+ *   VFML_CONV_MFMA2A the ACTIVATION operand as one f16 instead: a_hi w_hi + a_hi w_lo.  The weights keep their 22 bits;
+ *                    the activations' rounding is independent from pixel to pixel and iteration to iteration, where a
+ *                    rounded weight is the same perturbation everywhere (measured at 1080p: 10-30x less end-point
+ *                    error than VFML_CONV_MFMA2 on the same layer), and the activation operand is the larger stream;
+ *   VFML_CONV_MFMA1  both operands as one f16: a_hi w_hi - plain f16 inputs, f32 accumulate ("fp16" arithmetic).
  * The lo halves that are not used are not fetched.  Where a tile shape / loader combination is not built for the
  * reduced count the call runs with three MFMAs (never less accurate than asked). */
-       VFML_CONV_MFMA2 = 2, VFML_CONV_MFMA1 = 4 };
+       VFML_CONV_MFMA2 = 2, VFML_CONV_MFMA1 = 4, VFML_CONV_MFMA2A = 8 };
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
 

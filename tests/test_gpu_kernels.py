@@ -695,7 +695,7 @@ def _f16(t):
     return t.half().double()
 
 
-@pytest.mark.parametrize("mfma", [2, 1])
+@pytest.mark.parametrize("mfma", [2, "2a", 1])
 @pytest.mark.parametrize("cin,cout,kh,kw,stride,src16,cblock", [
     (64, 192, 3, 3, 1, True, True),       # 128 x 192 / 192 x 128 tiles, uniform-step loader
     (96, 128, 1, 5, 1, True, False),      # tap order: the general loader
@@ -706,12 +706,12 @@ def _f16(t):
     (4, 64, 7, 7, 2, False, False),       # encoder stem
 ])
 def test_conv2d_reduced_mfma_counts_drop_exactly_the_lo_terms(gpu, mfma, cin, cout, kh, kw, stride, src16, cblock):
-    """VFML_CONV_MFMA2 / _MFMA1: the result equals a float64 convolution of (activations rounded to split rows |
-    to ONE f16) with (weights rounded to one f16, nearest) - i.e. exactly the a*w_lo (and a_lo*w) terms are gone, with
-    an unbiased rounding - and differs from the full-precision result by the f16 rounding of that operand."""
+    """VFML_CONV_MFMA2 / _MFMA2A / _MFMA1: the result equals a float64 convolution of the operands with the weights
+    (2, 1) and / or the activations ("2a", 1) rounded to ONE f16, to nearest - i.e. exactly the a*w_lo and / or a_lo*w
+    terms are gone, with an unbiased rounding - and differs from the full-precision result by that rounding."""
     from vfml import hip
     from vfml.weights import pack_conv_weight
-    g = torch.Generator().manual_seed(31 + mfma)
+    g = torch.Generator().manual_seed(31 + {2: 2, "2a": 3, 1: 1}[mfma])
     n, H, W = 2, 17, 22
     x = torch.randn(n, cin, H, W, generator=g)
     wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
@@ -719,8 +719,8 @@ def test_conv2d_reduced_mfma_counts_drop_exactly_the_lo_terms(gpu, mfma, cin, co
     ph, pw = kh // 2, kw // 2
     w = as_weight(pack_conv_weight(wt, cblock=cblock), cout, "f16x3", order=int(cblock))
     # the kernel sees the weights times the power-of-two split scale, rounded to f16, then divides the scale out
-    wq = _f16(wt * w.scale) / w.scale
-    xq = _f16(x) if mfma == 1 else x.double()
+    wq = _f16(wt * w.scale) / w.scale if mfma in (2, 1) else wt.double()
+    xq = _f16(x) if mfma in ("2a", 1) else x.double()
     emu = F.conv2d(xq, wq, b.double(), stride=stride, padding=(ph, pw)).float()
     full = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=(ph, pw)).float()
     ho, wo = emu.shape[-2:]

@@ -81,31 +81,34 @@ def main():
           f"|flow| mean {float(ref.abs().mean()):.3f} px")
     rows = []
     for layer in LAYERS:
-        for n in (2, 1):
-            if layer == "corr" and n == 2:
+        for n in (2, "2a", 1):
+            if layer == "corr" and n != 1:
                 continue
             e = epe(field({layer: n}), ref)
             t = timed({layer: n})
             rows.append({"layer": layer, "mfma": n, "epe": e, "ms": t, "saved_ms": t_ref - t})
-            print(f"  {layer:34s} mfma {n}: dEPE {e:.3e} px  field {t:7.2f} ms  saved {t_ref - t:6.2f} ms", flush=True)
+            print(f"  {layer:34s} mfma {n!s:>2}: dEPE {e:.3e} px  field {t:7.2f} ms  saved {t_ref - t:6.2f} ms", flush=True)
 
-    # greedy: per layer the options are (2, 1); take steps in order of error per saved ms
-    plan, spent = {}, 0.0
+    # greedy: per layer the options are ("2a", 2, 1); take steps in order of error per saved ms
+    plan, spent, saved = {}, 0.0, {}
     opts = sorted([r for r in rows if r["saved_ms"] > 0.02], key=lambda r: r["epe"] / r["saved_ms"])
     for r in opts:
-        cur = plan.get(r["layer"], 3)
-        if r["mfma"] >= cur:
+        cur = plan.get(r["layer"])
+        if cur is not None and saved[r["layer"]] >= r["saved_ms"]:
             continue
         prev = next((q["epe"] for q in rows if q["layer"] == r["layer"] and q["mfma"] == cur), 0.0)
         if spent - prev + r["epe"] > args.budget:
             continue
         spent += r["epe"] - prev
         plan[r["layer"]] = r["mfma"]
+        saved[r["layer"]] = r["saved_ms"]
     e_plan = epe(field(plan), ref)
     t_plan = timed(plan)
     print(f"greedy plan (budget {args.budget:.1e}, sum of single-layer errors {spent:.2e}): {json.dumps(plan)}")
     print(f"  combined: dEPE {e_plan:.3e} px vs all-3, field {t_plan:.2f} ms (all-3 {t_ref:.2f} ms)")
-    for name, p in (("all-2", {"": 2}), ("all-1", {"": 1})):
+    ub2a = {UB: "2a", "corr": 1}
+    print(f"  update block '2a' + corr 1: dEPE {epe(field(ub2a), ref):.3e} px, field {timed(ub2a):.2f} ms")
+    for name, p in (("all-2w", {"": 2}), ("all-2a", {"": "2a"}), ("all-1", {"": 1})):
         print(f"  {name}: dEPE {epe(field(p), ref):.3e} px, field {timed(p):.2f} ms")
     if args.json:
         with open(args.json, "w") as f:

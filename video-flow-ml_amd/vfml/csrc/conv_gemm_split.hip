@@ -80,7 +80,7 @@ struct SplitArgs {
   int cswap;                    // VFML_CONV_SWAP_CROSS
   int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
   double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
-  int nm;                       // MFMAs per product: 3, 2 (weights as plain f16) or 1 (both operands plain f16)
+  int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -228,10 +228,12 @@ __device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* s
 // IN16: the sources are already in the split-row format (VFML_FMT_S16: per pixel and 8-channel group
 // 16 B of hi halves then 16 B of lo halves), so the two 16-byte loads of a unit ARE its hi and lo
 // LDS images and no conversion happens in the loop.
-// NM: MFMAs per product (SplitArgs::nm): 3 = hi*hi + hi*lo + lo*hi; 2 = the weight operand as plain f16
-// (hi*hi + lo*hi); 1 = both operands plain f16 (hi*hi).
+// NM: which terms of the split product are formed (SplitArgs::nm): 3 = a_hi w_hi + a_hi w_lo + a_lo w_hi;
+// 2 = the weight operand as plain f16 (a_hi w_hi + a_lo w_hi); 4 = the activation operand as plain f16
+// (a_hi w_hi + a_hi w_lo); 1 = both operands plain f16 (a_hi w_hi).
 template <int BN, int WM, int WN, bool BIGC, bool IN16, int NM = 3>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const SplitArgs a) {
+  constexpr bool ALO = NM == 3 || NM == 2, BLO = NM == 3 || NM == 4;
   constexpr int NT = WM * WN * 64;  // threads: 256 (4 waves) or 512 (8 waves, finer MFMA interleave per SIMD)
   constexpr int LR = NT / 4;        // rows covered by one pass of the loader (4 k-groups per row)
   constexpr int TM = BM / (WM * 32);
@@ -427,20 +429,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = sAh[oa + (2 * ks + half) * RSA + i * 32];
-        if constexpr (NM >= 2) al[i] = sAl[oa + (2 * ks + half) * RSA + i * 32];
+        if constexpr (ALO) al[i] = sAl[oa + (2 * ks + half) * RSA + i * 32];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = sBh[ob + (2 * ks + half) * RSB + j * 32];
-        if constexpr (NM >= 3) bl[j] = sBl[ob + (2 * ks + half) * RSB + j * 32];
+        if constexpr (BLO) bl[j] = sBl[ob + (2 * ks + half) * RSB + j * 32];
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          if constexpr (NM >= 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          if constexpr (NM >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (BLO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (ALO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
   };
@@ -552,13 +554,14 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 // FASTK: the uniform-step loader (SplitArgs::fastk) as a compile-time choice - with both loaders in one
 // body hipcc stops unrolling the MFMA loops of the larger tiles and the accumulators go to scratch.
 // CSWAP: VFML_CONV_SWAP_CROSS as a compile-time choice (GEMM form only; a runtime branch in the MFMA loop spills).
-// NM: MFMAs per product (SplitArgs::nm).  2: the weight operand is taken as plain f16 - its lo slots are never
+// NM: terms of the split product (SplitArgs::nm).  2: the weight operand is taken as plain f16 - its lo slots are never
 // fetched (those lanes of a weight piece carry an out-of-range offset) nor read, a product is a_hi b + a_lo b; the
-// operand may then be ONE f16 plane without a lo plane at all (SplitArgs::bhi).  1: the activation operand as
-// plain f16 too (its lo slots are not fetched either), one MFMA per product.
+// operand may then be ONE f16 plane without a lo plane at all (SplitArgs::bhi).  4: the ACTIVATION operand as plain
+// f16 instead (its lo slots not fetched: a_hi b_hi + a_hi b_lo).  1: both, one MFMA per product.
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
-  constexpr bool BHI = NM < 3;
+  constexpr bool BHI = NM == 2 || NM == 1;     // weight lo slots unused
+  constexpr bool AHI = NM == 4 || NM == 1;     // activation lo slots unused
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
   constexpr int AP = TBM / (8 * NW), BP = TBN / (8 * NW);  // 1-KiB pieces (8 rows x 128 B) per wave per K step
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       for (int j = 0; j < AP; ++j) {
         rp0[j] += a.abias + kg * 32 + hl * 16;
         tapok[j] = ~tapok[j];
-        if (NM == 1 && hl) rp0[j] |= (int)0x80000000;      // lo slots of the activations: never fetched
+        if (AHI && hl) rp0[j] |= (int)0x80000000;      // lo slots of the activations: never fetched
       }
       scb = sky = skx = 0;
     }
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
     const int tap = kok ? kky * a.kw + kkx : 63;   // bit 63 is never set (kh*kw < 64, host check)
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
-      const bool ok = ((tapok[j] >> tap) & 1ull) && !(NM == 1 && hl);
+      const bool ok = ((tapok[j] >> tap) & 1ull) && !(AHI && hl);
       va[j] = ok ? (s1 ? rp1[j] : rp0[j]) + tapoff : OOB;
     }
     if (a.korder) {          // next tap of the same 32 channels; after the last tap the next 32 channels
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64)) + i * 4096);
-        if constexpr (NM >= 2) al[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64 + 16)) + i * 4096);
+        if constexpr (!AHI) al[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 64 + 16)) + i * 4096);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #ifndef VFML_EXPERIMENT_2MFMA     // timing / accuracy experiment: second operand (weights) as plain f16
             if constexpr (!BHI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #endif
-            if constexpr (NM >= 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            if constexpr (!AHI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
           }
 #ifndef VFML_ISSUE_GROUPS
 #define VFML_ISSUE_GROUPS (TM * TN)      // the first half of the step: the second half covers the pieces' L2 latency
@@ -1024,6 +1027,7 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
     if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
     if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
+    if (a.nm == 2 && a.bhi) { vfml_set_error("vfml_conv2d_split: a weight operand without lo plane needs the uniform-step GEMM form"); return 1; }
     a.nm = 3;       // (the general-loader GEMM form exists at full precision only: never less accurate than asked)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
   }
@@ -1031,12 +1035,14 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     if constexpr (TM * TN >= 2) {
       if (a.fastk) {
         if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2>(a, s);
+        if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, true, false, 4>(a, s);
         if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, true, false, 1>(a, s);
         return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
       }
     }
     a.fastk = 0; a.abias = 0;
     if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, false, false, 2>(a, s);
+    if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, false, false, 4>(a, s);
     if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, false, false, 1>(a, s);
     return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
   }
@@ -1068,6 +1074,7 @@ template <int BN, int WM, int WN, bool BIGC, bool IN16>
 int launch(const SplitArgs& a, hipStream_t s) {
   if (a.nm == 1) return launch_nm<BN, WM, WN, BIGC, IN16, 1>(a, s);
   if (a.nm == 2) return launch_nm<BN, WM, WN, BIGC, IN16, 2>(a, s);
+  if (a.nm == 4) return launch_nm<BN, WM, WN, BIGC, IN16, 4>(a, s);
   return launch_nm<BN, WM, WN, BIGC, IN16, 3>(a, s);
 }
 
@@ -1379,10 +1386,13 @@ extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, flo
 extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
                                  int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
-  VFML_REQUIRE((d->flags & ~(VFML_CONV_SWAP_CROSS | VFML_CONV_MFMA2 | VFML_CONV_MFMA1)) == 0, "vfml_conv2d_split: unknown flag bits");
-  VFML_REQUIRE(!((d->flags & VFML_CONV_MFMA2) && (d->flags & VFML_CONV_MFMA1)) &&
-               !((d->flags & VFML_CONV_SWAP_CROSS) && (d->flags & (VFML_CONV_MFMA2 | VFML_CONV_MFMA1))),
-               "vfml_conv2d_split: VFML_CONV_MFMA2 / _MFMA1 / _SWAP_CROSS exclude one another");
+  {
+    const int pbits = d->flags & (VFML_CONV_MFMA2 | VFML_CONV_MFMA1 | VFML_CONV_MFMA2A);
+    VFML_REQUIRE((d->flags & ~(VFML_CONV_SWAP_CROSS | VFML_CONV_MFMA2 | VFML_CONV_MFMA1 | VFML_CONV_MFMA2A)) == 0,
+                 "vfml_conv2d_split: unknown flag bits");
+    VFML_REQUIRE((pbits & (pbits - 1)) == 0 && !((d->flags & VFML_CONV_SWAP_CROSS) && pbits),
+                 "vfml_conv2d_split: VFML_CONV_MFMA2 / _MFMA2A / _MFMA1 / _SWAP_CROSS exclude one another");
+  }
   VFML_REQUIRE(in_fmt == VFML_FMT_S16 || ((d->flags & VFML_CONV_SWAP_CROSS) == 0 && d->out_t == nullptr),
                "vfml_conv2d_split: out_t / VFML_CONV_SWAP_CROSS need split-row sources");
   if (d->stats_part) {
@@ -1458,7 +1468,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   SplitArgs a;
   a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0; a.bhi = 0;
   a.stats_part = d->stats_part;
-  a.nm = (d->flags & VFML_CONV_MFMA1) ? 1 : ((d->flags & VFML_CONV_MFMA2) || bhi) ? 2 : 3;
+  a.nm = (d->flags & VFML_CONV_MFMA1) ? 1 : (d->flags & VFML_CONV_MFMA2A) ? (bhi ? 1 : 4) : ((d->flags & VFML_CONV_MFMA2) || bhi) ? 2 : 3;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)
   const float* base = (two && d->in1 < d->in0) ? d->in1 : d->in0;

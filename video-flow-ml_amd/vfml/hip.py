@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 KORDER_TAP, KORDER_CBLOCK = 0, 1   # K-axis order of split weight planes (include/vfml.h)
-CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1 = 1, 2, 4   # vfml_conv_desc.flags
+CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1, CONV_MFMA2A = 1, 2, 4, 8   # vfml_conv_desc.flags
 
 
 class ConvDesc(ctypes.Structure):
@@ -264,8 +264,8 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
            out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
-    (channel slices of wider NHWC buffers).  mfma: MFMAs per product of the split-f16 kernel (3; 2 = weights as
-    plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA1)."""
+    (channel slices of wider NHWC buffers).  mfma: terms of the split-f16 product (3; 2 or "2w" = weights as plain
+    f16; "2a" = activations as plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA2A / _MFMA1)."""
     d = ConvDesc()
     d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
     d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
@@ -280,9 +280,11 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.aux1, d.ld_aux1 = (_ptr(_dev(aux1), aux1_off) if aux1 is not None else None), ld_aux1
     d.addend, d.ld_addend = (_ptr(_dev(addend), addend_off) if addend is not None else None), ld_addend
     d.out_t, d.ld_out_t = (_ptr(_dev(out_t), out_t_off) if out_t is not None else None), ld_out_t
-    if mfma not in (1, 2, 3) or (swap_cross and mfma != 3):
-        raise ValueError(f"mfma={mfma}: 1, 2 or 3 (3 with swap_cross)")
-    d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, 1: CONV_MFMA1}[mfma]
+    if mfma == "2w":
+        mfma = 2
+    if mfma not in (1, 2, 3, "2a") or (swap_cross and mfma != 3):
+        raise ValueError(f"mfma={mfma!r}: 1, 2 ('2w'), '2a' or 3 (3 with swap_cross)")
+    d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, "2a": CONV_MFMA2A, 1: CONV_MFMA1}[mfma]
     d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
@@ -314,7 +316,8 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
              and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
                                   weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
-                                  min(mfma, 2) if (is_split and weight.lo is None) else mfma),
+                                  ({3: 2, 2: 2, "2a": 1, 1: 1}[mfma] if (is_split and weight.lo is None)
+                                   else {"2a": 4}.get(mfma, mfma))),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)

@@ -165,8 +165,8 @@ class MOFNetHIP(_Holder):
 
     def _nm(self, layer):
         """MFMAs per product for `layer` (a conv_spec name, '.iter' / '.ctx' for the two parts of a GRU gate
-        convolution, or 'corr' for the correlation GEMMs): 3 = fp32-grade split product, 2 = weights as plain f16,
-        1 = both operands plain f16.  'f16x3' / 'f16x2' / 'f16' = 3 / 2 / 1 everywhere; 'mixed' = cfg.mfma_plan,
+        convolution, or 'corr' for the correlation GEMMs): 3 = fp32-grade split product, 2 / "2w" = weights as plain f16,
+        "2a" = activations as plain f16, 1 = both operands plain f16.  'f16x3' / 'f16x2' / 'f16' = 3 / 2 / 1 everywhere; 'mixed' = cfg.mfma_plan,
         {name prefix: count}, longest prefix wins, 3 where nothing matches."""
         p = self._precision()
         if p == "f16x3":
@@ -180,17 +180,19 @@ class MOFNetHIP(_Holder):
             best, nm = -1, 3
             for prefix, n in plan.items():
                 if layer.startswith(prefix) and len(prefix) > best:
-                    best, nm = len(prefix), int(n)
-            if nm not in (1, 2, 3):
-                raise ValueError(f"cfg.mfma_plan[{layer!r}] = {nm}: 1, 2 or 3")
-        if layer == "corr" and nm == 2:
-            nm = 3       # a volume and its transpose must stay the same numbers: the symmetric counts only
+                    best, nm = len(prefix), (n if isinstance(n, str) else int(n))
+            if nm == "2w":
+                nm = 2
+            if nm not in (1, 2, "2a", 3):
+                raise ValueError(f"cfg.mfma_plan[{layer!r}] = {nm!r}: 1, 2 ('2w'), '2a' or 3")
+        if layer == "corr" and nm in (2, "2a"):
+            nm = 3       # a volume and its transpose must stay the same numbers: the symmetric forms only
         return nm
 
     def _plan_key(self):
         """The arithmetic as part of a cached frame's identity."""
         p = self._precision()
-        return (p, tuple(sorted((getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
+        return (p, tuple(sorted((k, str(v)) for k, v in (getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, name, numel, device, dtype=torch.float32, zero=False):
