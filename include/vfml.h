@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 15
+#define VFML_ABI_VERSION 16
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -205,6 +205,16 @@ int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* 
                      const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, void* stream);
 /* out_fmt VFML_FMT_S16: channels are written as split rows; the channel count is rounded up to a
  * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0). */
+
+/* The same lookup with the pyramid pointers read from a DEVICE table at run time: table[m * levels + l] is what
+ * pyr[m * levels + l] is above.  A launch recorded in a HIP graph (the update iterations of a field are a fixed launch
+ * sequence, replayed per field) then follows whatever pyramids the table names when the graph runs.
+ * vfml_ptr_table_set writes n <= 48 device pointers into such a table, asynchronously on `stream` (the values travel as
+ * kernel arguments: no host buffer has to outlive the call). */
+int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
+                              int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
+                              float* out, int ld_out, int out_fmt, void* stream);
+int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream);
 
 /* coords1 += delta (4 floats per pixel: fwd x,y, bwd x,y); flow = coords1 - grid is written to
  * flow_a[p*ld_a..+4] and flow_b[p*ld_b..+4] (either may be NULL).  h,w give the pixel grid,

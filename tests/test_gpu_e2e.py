@@ -400,3 +400,46 @@ def test_bof_720p_seq9_fp16_config(gpu):
     # plain f16 operands through ~100 dependent layers and 12 iterations: well outside the fp32 tolerance by design;
     # bounded here so that a broken kernel (not a rounding) fails
     assert got["f16"][0] < 0.1 * max(1.0, float(ref.abs().mean())), got
+
+
+def test_graph_replay_of_the_iteration_body_is_bit_identical(gpu):
+    """The update iterations of a field run as one replayed HIP graph from the third field of a configuration on
+    (eager, capture + replay, replay ...): every field equals the eager engine's, along a sliding job, across a change
+    of geometry and back (a workspace reallocation drops the graphs), and after new weights are loaded."""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml import build_network, get_cfg
+    from vfml.synth import synthetic_clip
+    from vfml.weights import seeded_state_dict
+    nets = {}
+    for use in (True, False):
+        cfg = get_cfg()
+        cfg.use_graph = use
+        net = build_network(cfg)
+        net.load_state_dict(seeded_state_dict(cfg, 0))
+        nets[use] = net.cuda().eval()
+    procs = {}
+    for use, net in nets.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            procs[use] = VideoFlowProcessor("cuda", sequence_length=5)
+        procs[use].core.model = net
+    frames = synthetic_clip(9, 128, 160)
+    small = [np.ascontiguousarray(f[:96, :128]) for f in frames]
+    clips = {use: (p.upload_clip(frames), p.upload_clip(small)) for use, p in procs.items()}
+    replays = 0
+    for which, idxs in ((0, range(9)), (1, range(2, 6)), (0, range(3, 7))):
+        for i in idxs:
+            a = procs[True].compute_optical_flow_resident(clips[True][which], i)
+            b = procs[False].compute_optical_flow_resident(clips[False][which], i)
+            assert torch.equal(a, b), (which, i)
+        replays += sum(1 for g in nets[True]._graphs.values() if not isinstance(g, str))
+    assert replays >= 3 and not nets[False]._graphs          # graphs were captured and used on one side only
+    # the full-output call (another launch sequence) and new weights
+    for seed in (0, 1):
+        for use, net in nets.items():
+            net.load_state_dict(seeded_state_dict(get_cfg(), seed))
+        outs = {use: [net.forward_u8(clips[use][0][2:7], return_lowres=False)[0].clone() for _ in range(3)]
+                for use, net in nets.items()}
+        assert all(torch.equal(outs[True][k], outs[False][0]) for k in range(3)), seed

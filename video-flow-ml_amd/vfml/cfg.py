@@ -46,4 +46,6 @@ def get_cfg():
         #   'f32'   exact fp32 on the f32 matrix cores (v_mfma_f32_32x32x2_f32), 5.3x slower peak
         precision="f16x3",
         mfma_plan=None,
+        # the update iterations of a field as one replayed HIP graph (None: on unless VFML_GRAPH=0; results identical)
+        use_graph=None,
     )

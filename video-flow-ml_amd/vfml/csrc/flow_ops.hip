@@ -19,6 +19,9 @@ static_assert(FIXED_LEVELS == 4, "corr_lookup_fixed_kernel selects among four le
 
 struct LookupArgs {
   const float* pyr[MAX_MAPS][MAX_LEVELS];   // one pyramid per query map (problem); rows = that map's queries
+  const float* const* table;                // or (non-null) a DEVICE array [map * levels + level] of the same pointers,
+                                            // read at run time: the launch can then sit in a captured graph while the
+                                            // pyramids it looks up change from replay to replay
   int hl[MAX_LEVELS], wl[MAX_LEVELS], ld[MAX_LEVELS];
   int levels, radius, nq, q_per_map;
   const float* coords; int ld_coords;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
       const int xx = x0 + px, yy = y0 + py;
       float v = 0.f;
       if (xx >= 0 && xx < a.wl[l] && yy >= 0 && yy < a.hl[l])
-        v = a.pyr[map][l][(int64_t)qq * a.ld[l] + (int64_t)yy * a.wl[l] + xx];
+        v = (a.table ? a.table[map * a.levels + l] : a.pyr[map][l])[(int64_t)qq * a.ld[l] + (int64_t)yy * a.wl[l] + xx];
       patch[wv][l][idx] = v;
       if (idx == 0) {
         frac[wv][l][0] = x - fx0;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
     int lw[FIXED_LEVELS], lh[FIXED_LEVELS];
 #pragma unroll
     for (int l = 0; l < FIXED_LEVELS; ++l) {
-      lp[l] = l < a.levels ? a.pyr[map][l] + (int64_t)qq * a.ld[l] : nullptr;
+      lp[l] = l < a.levels ? (a.table ? a.table[map * a.levels + l] : a.pyr[map][l]) + (int64_t)qq * a.ld[l] : nullptr;
       lw[l] = a.wl[l];
       lh[l] = a.hl[l];
     }
@@ -318,15 +321,52 @@ inline int grid_for(int64_t items, int block) {
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// n device pointers -> a device table (vfml_corr_lookup_indirect reads it): the values travel as kernel arguments, so
+// no host staging buffer has to outlive the call
+constexpr int MAX_TABLE = MAX_MAPS * MAX_LEVELS;
+struct PtrTable { const void* p[MAX_TABLE]; };
+__global__ void ptr_table_kernel(const PtrTable t, int n, const void** dst) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = t.p[threadIdx.x];
+}
+
 }  // namespace
+
+extern "C" int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream) {
+  VFML_REQUIRE(table && ptrs && n >= 1 && n <= MAX_TABLE, "vfml_ptr_table_set: 1..%d pointers", MAX_TABLE);
+  PtrTable t;
+  for (int i = 0; i < MAX_TABLE; ++i) t.p[i] = i < n ? ptrs[i] : nullptr;
+  hipLaunchKernelGGL(ptr_table_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), t, n,
+                     reinterpret_cast<const void**>(table));
+  return vfml_check_launch("vfml_ptr_table_set");
+}
+
+static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
+                            const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
+                            int ld_coords, float* out, int ld_out, int out_fmt, void* stream);
 
 extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                 int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
                                 float* out, int ld_out, int out_fmt, void* stream) {
+  VFML_REQUIRE(pyr, "vfml_corr_lookup: null pointer");
+  return corr_lookup_impl(pyr, nullptr, hl, wl, ld, levels, radius, nmaps, q_per_map, coords, ld_coords, out, ld_out, out_fmt,
+                          stream);
+}
+
+extern "C" int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
+                                         int levels, int radius, int nmaps, int q_per_map, const float* coords,
+                                         int ld_coords, float* out, int ld_out, int out_fmt, void* stream) {
+  VFML_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7u) == 0, "vfml_corr_lookup_indirect: null / misaligned table");
+  return corr_lookup_impl(nullptr, table, hl, wl, ld, levels, radius, nmaps, q_per_map, coords, ld_coords, out, ld_out,
+                          out_fmt, stream);
+}
+
+static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
+                            const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
+                            int ld_coords, float* out, int ld_out, int out_fmt, void* stream) {
   VFML_REQUIRE(nmaps >= 1 && nmaps <= MAX_MAPS && q_per_map > 0, "vfml_corr_lookup: nmaps=%d out of [1,%d] or empty maps", nmaps, MAX_MAPS);
   const int nq = nmaps * q_per_map;
   VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
-  VFML_REQUIRE(pyr && hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
+  VFML_REQUIRE(hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
   VFML_REQUIRE(levels >= 1 && levels <= MAX_LEVELS, "vfml_corr_lookup: levels=%d out of [1,%d]", levels, MAX_LEVELS);
   VFML_REQUIRE(radius >= 1 && radius <= MAX_RADIUS, "vfml_corr_lookup: radius=%d out of [1,%d]", radius, MAX_RADIUS);
   VFML_REQUIRE(ld_coords >= 2, "vfml_corr_lookup: bad ld_coords");
@@ -337,12 +377,13 @@ extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, cons
                  "vfml_corr_lookup: split-row output needs a 32-byte aligned out and ld_out %% 8 == 0");
   LookupArgs a;
   a.out16 = out_fmt == VFML_FMT_S16;
+  a.table = table;
   for (int m = 0; m < MAX_MAPS; ++m)
     for (int l = 0; l < MAX_LEVELS; ++l) a.pyr[m][l] = nullptr;
   for (int l = 0; l < levels; ++l) {
     VFML_REQUIRE(hl[l] > 0 && wl[l] > 0 && ld[l] >= hl[l] * wl[l], "vfml_corr_lookup: bad level %d", l);
     a.hl[l] = hl[l]; a.wl[l] = wl[l]; a.ld[l] = ld[l];
-    for (int m = 0; m < nmaps; ++m) {
+    for (int m = 0; m < nmaps && pyr; ++m) {
       VFML_REQUIRE(pyr[m * levels + l], "vfml_corr_lookup: null pyramid pointer (map %d, level %d)", m, l);
       a.pyr[m][l] = pyr[m * levels + l];
     }

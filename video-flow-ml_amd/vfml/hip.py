@@ -91,6 +91,9 @@ def lib():
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                    c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
+    L.vfml_corr_lookup_indirect.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                            c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
+    L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
@@ -103,7 +106,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 15:
+    if L.vfml_abi_version() != 16:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -112,7 +115,8 @@ def lib():
 EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
-    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_coords_update", "vfml_coords_init",
+    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
+    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init",
     "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -404,19 +408,38 @@ def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):
            "vfml_to_s16")
 
 
-def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coords, out, out_off, ld_out,
-                out_fmt=FMT_F32):
-    """pyrs: list (one entry per query map) of lists (one flat float32 device tensor per level, rows =
-    that map's q_per_map queries).  Queries / coords / out rows are ordered map-major."""
-    if pyrs and torch.is_tensor(pyrs[0]):
-        pyrs = [pyrs]
-    nmaps, L = len(pyrs), len(pyrs[0])
-    ptrs = (c_void_p * (nmaps * L))(*[p.data_ptr() for m in pyrs for p in m])
+def ptr_table_set(table, tensors):
+    """Write the device pointers of `tensors` into `table` (an int64 device tensor), asynchronously on the current stream."""
+    n = len(tensors)
+    if not (table.is_cuda and table.dtype == torch.int64 and table.numel() >= n):
+        raise ValueError("ptr_table_set: table must be an int64 device tensor with room for the pointers")
+    ptrs = (c_void_p * n)(*[t.data_ptr() for t in tensors])
+    _check(lib().vfml_ptr_table_set(c_void_p(table.data_ptr()), ptrs, n, _stream()), "vfml_ptr_table_set")
 
-    def launch():
-        _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
-                                      nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
-                                      _ptr(_dev(out), out_off), ld_out, out_fmt, _stream()), "vfml_corr_lookup")
+
+def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coords, out, out_off, ld_out,
+                out_fmt=FMT_F32, table=None, nmaps=None):
+    """pyrs: list (one entry per query map) of lists (one flat float32 device tensor per level, rows =
+    that map's q_per_map queries).  Queries / coords / out rows are ordered map-major.
+    table (with nmaps): instead of `pyrs`, an int64 device tensor holding the same pointers, map-major
+    (ptr_table_set), read when the kernel runs (vfml_corr_lookup_indirect)."""
+    L = len(hl)
+    if table is not None:
+        def launch():
+            _check(lib().vfml_corr_lookup_indirect(c_void_p(table.data_ptr()), (c_int32 * L)(*hl), (c_int32 * L)(*wl),
+                                                   (c_int32 * L)(*ld), L, radius, nmaps, q_per_map,
+                                                   _ptr(_dev(coords), coords_off), ld_coords, _ptr(_dev(out), out_off),
+                                                   ld_out, out_fmt, _stream()), "vfml_corr_lookup_indirect")
+    else:
+        if pyrs and torch.is_tensor(pyrs[0]):
+            pyrs = [pyrs]
+        nmaps, L = len(pyrs), len(pyrs[0])
+        ptrs = (c_void_p * (nmaps * L))(*[p.data_ptr() for m in pyrs for p in m])
+
+        def launch():
+            _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
+                                          nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
+                                          _ptr(_dev(out), out_off), ld_out, out_fmt, _stream()), "vfml_corr_lookup")
     if _PROFILE_HBM is None:
         launch()
         return

@@ -82,6 +82,8 @@ class MemFlowNetHIP(MOFNetHIP):
         self._packed_key = None
         self._packed_serial = 0
         self._ws = {}
+        self._graphs = {}
+        self._pyr_free = []
         self._att_planes = {}            # attention matrices as plain f16 planes (hip.PlainWeight), per pair of a pass
         self._feat_cache = collections.OrderedDict()
 

@@ -70,6 +70,7 @@ class MOFNetHIP(_Holder):
         self._packed_key = None
         self._packed_serial = 0
         self._ws = {}
+        self._graphs = {}
         self._pyr_free = []
         import collections
         self._feat_cache = collections.OrderedDict()
@@ -146,6 +147,7 @@ class MOFNetHIP(_Holder):
                     sw.order = hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP
                     P[name] = (sw, b)
         self._packed, self._packed_key = P, key
+        self._graphs.clear()              # captured launches hold the old planes' addresses
         self._packed_serial += 1          # new weights: cached encoder outputs are stale
         self._feat_cache.clear()
         return P
@@ -199,13 +201,48 @@ class MOFNetHIP(_Holder):
         """Named scratch buffer, cached per exact size (a resolution change reallocates)."""
         t = self._ws.get(name)
         if t is None or t.numel() != numel or t.device != device or t.dtype != dtype:
+            if t is not None:
+                self._graphs.clear()       # captured launches hold this buffer's address
             t = (torch.zeros if zero else torch.empty)(int(numel), device=device, dtype=dtype)
             self._ws[name] = t
         return t
 
     def release_workspace(self):
+        self._graphs.clear()
         self._ws.clear()
         self._feat_cache.clear()
+
+    # ------------------------------------------------------------------ graph replay of the iteration body
+    GRAPHS_KEPT = 8
+
+    def _use_graph(self):
+        use = getattr(self.cfg, "use_graph", None)
+        if use is None:
+            use = os.environ.get("VFML_GRAPH", "1") != "0"
+        return bool(use) and hip._PROFILE is None       # (per-launch events of the roofline pass cannot be captured)
+
+    def _run_body(self, body, key, dev):
+        """Run `body` (a fixed sequence of kernel launches on fixed buffers): eagerly the first time a configuration
+        is seen (workspaces get allocated, kernel attributes set), captured into a HIP graph the second time, replayed
+        afterwards.  The launches go to torch's current stream through the C ABI, which during capture is the capture
+        stream.  Anything that moves a buffer the launches address (a workspace reallocation, new weights) drops the
+        graphs."""
+        if not self._use_graph():
+            body()
+            return
+        st = self._graphs.get(key)
+        if st is None:
+            body()
+            while len(self._graphs) >= self.GRAPHS_KEPT:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = "seen"
+            return
+        if st == "seen":
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                body()
+            self._graphs[key] = st = g
+        st.replay()
 
     # ------------------------------------------------------------------ encoder
     def _encoder(self, prefix, x, n, H, W, P, dev, out, ldo, out_off, epilogue, split, out_fmt=hip.FMT_F32):
@@ -552,94 +589,113 @@ class MOFNetHIP(_Holder):
             delta = self._buf("delta", MP * 4, dev)
             coords1 = self._buf("coords1", MP * 4, dev)
 
-            hip.coords_init(coords1, M, h, w)
-            hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
-                              fmt_b=AF)
-            ub = "update_block"
-            mf = self._nm if self._split() else (lambda layer: 3)     # MFMAs per product of a layer (cfg.precision)
-            for it in range(cfg.decoder_depth):
-                # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
-                # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
-                # more per iteration (through the temporal fusion), so the last iterations run on the centres
-                # that still matter only: GRU + flow head on `ng`, lookups + motion encoder on `nm` of them.
-                left = cfg.decoder_depth - 1 - it
-                ng = min(M, left + 1) if pick_only and not self.tri_frame else M
-                nm = min(M, left + 2) if pick_only and not self.tri_frame else M
-                # K5
-                hip.corr_lookup(pyrs["f"][:nm], hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF)
-                hip.corr_lookup(pyrs["b"][:nm], hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF)
-                # motion encoder
-                wgt, b = P[f"{ub}.encoder.convc1"]
-                hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
-                           in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc1"))
-                wgt, b = P[f"{ub}.encoder.convc2"]
-                hip.conv2d(c1, 256, 256, nm, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
-                           in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc2"))
-                wgt, b = P[f"{ub}.encoder.convf1"]
-                hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
-                           out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
-                wgt, b = P[f"{ub}.encoder.convf2"]
-                hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf2"))
-                wgt, b = P[f"{ub}.encoder.conv"]
-                hip.conv2d(cf, 256, 256, nm, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.conv"))
-                # temporal stack fusion: 3x1 conv along the frame axis of the motion features
-                wgt, b = P[f"{ub}.tprop"]
-                if self.tri_frame:     # every centre frame is its own problem: its neighbours are the zero padding
-                    hip.conv2d(G, 128, GLD, M, 1, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
-                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.tprop"))
-                else:
-                    # (on the first nm frames: row nm-1 of a shortened stack sees zero padding where its lower
-                    # neighbour was - that row is not among the ng < nm the GRU reads)
-                    hip.conv2d(G, 128, GLD, 1, nm, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
-                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.tprop"))
-                # SepConvGRU, horizontal then vertical
-                for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
-                    wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
-                    # [z | r*h] = gates(conv([h | motion | temporal]) + context part)
-                    hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
-                               in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
-                               epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
-                               addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF,
-                               mfma=mf(f"{ub}.gru.convzr{k}.iter"))
-                    wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
-                    # h = (1 - z) h + z tanh(conv([r*h | motion | temporal]) + context part), in place
-                    hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
-                               in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
-                               epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
-                               aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
-                               in_fmt=AF, out_fmt=AF, aux_fmt=AF, mfma=mf(f"{ub}.gru.convq{k}.iter"))
-                # flow head
-                wgt, b = P[f"{ub}.flow_head.conv1"]
-                hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.flow_head.conv1"))
-                wgt, b = P[f"{ub}.flow_head.conv2"]
-                hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF,
-                           mfma=mf(f"{ub}.flow_head.conv2"))
-                hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
-                                  flow_b_off=MF + 124, fmt_b=AF)
-
-            # mask head on the final hidden state, then K8 for every flow of the output tensor (pick_only: of
-            # the first centre frame, and its backward flow alone)
+            # ---- the update iterations + mask head + upsampling: a FIXED launch sequence for a given geometry,
+            # window length and arithmetic - only the correlation pyramids it looks up differ from field to field,
+            # and those are named by two device tables.  With cfg.use_graph the sequence is captured into a HIP
+            # graph the second time a configuration is seen and replayed from then on (~250 launches per field
+            # become one; same kernels, same order: bit-identical results).
+            tab_f = self._buf("pyr_table_f", 64, dev, torch.int64)
+            tab_b = self._buf("pyr_table_b", 64, dev, torch.int64)
+            hip.ptr_table_set(tab_f, [p for m in pyrs["f"] for p in m])
+            hip.ptr_table_set(tab_b, [p for m in pyrs["b"] for p in m])
             no = 1 if pick_only and not self.tri_frame else M
+            nflows = 1 if pick_only and not self.tri_frame else 2 * M
+            up_fixed = self._buf("up_out", nflows * H * W * 2, dev)
             mask = self._buf("mask", MP * 1152, dev)
-            wgt, b = P[f"{ub}.mask.0"]
-            hip.conv2d(G, 128, GLD, no, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                       epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.mask.0"))
-            wgt, b = P[f"{ub}.mask.2"]
-            hip.conv2d(fh, 256, 256, no, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF,
-                       mfma=mf(f"{ub}.mask.2"))
+
+            def body():
+                hip.coords_init(coords1, M, h, w)
+                hip.coords_update(coords1, None, M, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
+                                  fmt_b=AF)
+                ub = "update_block"
+                mf = self._nm if self._split() else (lambda layer: 3)     # MFMAs per product of a layer (cfg.precision)
+                for it in range(cfg.decoder_depth):
+                    # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
+                    # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
+                    # more per iteration (through the temporal fusion), so the last iterations run on the centres
+                    # that still matter only: GRU + flow head on `ng`, lookups + motion encoder on `nm` of them.
+                    left = cfg.decoder_depth - 1 - it
+                    ng = min(M, left + 1) if pick_only and not self.tri_frame else M
+                    nm = min(M, left + 2) if pick_only and not self.tri_frame else M
+                    # K5
+                    hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF,
+                                    table=tab_f, nmaps=nm)
+                    hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF,
+                                    table=tab_b, nmaps=nm)
+                    # motion encoder
+                    wgt, b = P[f"{ub}.encoder.convc1"]
+                    hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
+                               in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc1"))
+                    wgt, b = P[f"{ub}.encoder.convc2"]
+                    hip.conv2d(c1, 256, 256, nm, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+                               in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc2"))
+                    wgt, b = P[f"{ub}.encoder.convf1"]
+                    hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                               out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
+                    wgt, b = P[f"{ub}.encoder.convf2"]
+                    hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf2"))
+                    wgt, b = P[f"{ub}.encoder.conv"]
+                    hip.conv2d(cf, 256, 256, nm, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.conv"))
+                    # temporal stack fusion: 3x1 conv along the frame axis of the motion features
+                    wgt, b = P[f"{ub}.tprop"]
+                    if self.tri_frame:     # every centre frame is its own problem: its neighbours are the zero padding
+                        hip.conv2d(G, 128, GLD, M, 1, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
+                                   epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.tprop"))
+                    else:
+                        # (on the first nm frames: row nm-1 of a shortened stack sees zero padding where its lower
+                        # neighbour was - that row is not among the ng < nm the GRU reads)
+                        hip.conv2d(G, 128, GLD, 1, nm, Pn, wgt, b, 128, 3, 1, G, GLD, in0_off=MF, out_off=MT, pad_h=1,
+                                   epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.tprop"))
+                    # SepConvGRU, horizontal then vertical
+                    for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
+                        wgt, _ = P[f"{ub}.gru.convzr{k}.iter"]
+                        # [z | r*h] = gates(conv([h | motion | temporal]) + context part)
+                        hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 256, kh, kw, G, GLD, in0_off=HH, out_off=Z,
+                                   in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
+                                   epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
+                                   addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF,
+                                   mfma=mf(f"{ub}.gru.convzr{k}.iter"))
+                        wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
+                        # h = (1 - z) h + z tanh(conv([r*h | motion | temporal]) + context part), in place
+                        hip.conv2d(G, 128, GLD, ng, h, w, wgt, None, 128, kh, kw, G, GLD, in0_off=RH, out_off=HH,
+                                   in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
+                                   epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
+                                   aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
+                                   in_fmt=AF, out_fmt=AF, aux_fmt=AF, mfma=mf(f"{ub}.gru.convq{k}.iter"))
+                    # flow head
+                    wgt, b = P[f"{ub}.flow_head.conv1"]
+                    hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.flow_head.conv1"))
+                    wgt, b = P[f"{ub}.flow_head.conv2"]
+                    hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF,
+                               mfma=mf(f"{ub}.flow_head.conv2"))
+                    hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                                      flow_b_off=MF + 124, fmt_b=AF)
+
+                # mask head on the final hidden state, then K8 for every flow of the output tensor (pick_only: of
+                # the first centre frame, and its backward flow alone)
+                wgt, b = P[f"{ub}.mask.0"]
+                hip.conv2d(G, 128, GLD, no, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                           epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.mask.0"))
+                wgt, b = P[f"{ub}.mask.2"]
+                hip.conv2d(fh, 256, 256, no, h, w, wgt, b, 1152, 1, 1, mask, 1152, out_scale=0.25, in_fmt=AF,
+                           mfma=mf(f"{ub}.mask.2"))
+                if pick_only and not self.tri_frame:
+                    hip.convex_upsample(coords1, 0, 2, mask, 576, 1152, h, w, up_fixed)
+                else:
+                    for d in range(2):
+                        for c in range(M):
+                            hip.convex_upsample(coords1, c * Pn * 4, 2 * d, mask, c * Pn * 1152 + d * 576, 1152, h, w,
+                                                up_fixed, out_off=(d * M + c) * H * W * 2)
+
+            gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(),
+                    self._packed_serial, str(dev))
+            self._run_body(body, gkey, dev)
+            up = up_fixed.clone().view(nflows, H, W, 2)          # the caller owns its field; the fixed buffer is reused
             if pick_only and not self.tri_frame:
-                up = torch.empty(1, H, W, 2, device=dev, dtype=torch.float32)
-                hip.convex_upsample(coords1, 0, 2, mask, 576, 1152, h, w, up.view(-1))
                 return up.permute(0, 3, 1, 2).unsqueeze(0), None        # [1, 1, 2, H, W]: flow M of the full output
-            up = torch.empty(2 * M, H, W, 2, device=dev, dtype=torch.float32)
-            upf = up.view(-1)
-            for d in range(2):
-                for c in range(M):
-                    hip.convex_upsample(coords1, c * Pn * 4, 2 * d, mask, c * Pn * 1152 + d * 576, 1152, h, w, upf,
-                                        out_off=(d * M + c) * H * W * 2)
             # [2M,H,W,2] stored HWC; expose the reference's [B, 2M, 2, H, W] as a view
             flow = up.permute(0, 3, 1, 2).unsqueeze(0)
             low = None
