@@ -426,7 +426,7 @@ def test_graph_replay_of_the_iteration_body_is_bit_identical(gpu):
             procs[use] = VideoFlowProcessor("cuda", sequence_length=5)
         procs[use].core.model = net
     frames = synthetic_clip(9, 128, 160)
-    small = [np.ascontiguousarray(f[:96, :128]) for f in frames]
+    small = [np.ascontiguousarray(f[:128, :128]) for f in frames]
     clips = {use: (p.upload_clip(frames), p.upload_clip(small)) for use, p in procs.items()}
     replays = 0
     for which, idxs in ((0, range(9)), (1, range(2, 6)), (0, range(3, 7))):
@@ -443,3 +443,60 @@ def test_graph_replay_of_the_iteration_body_is_bit_identical(gpu):
         outs = {use: [net.forward_u8(clips[use][0][2:7], return_lowres=False)[0].clone() for _ in range(3)]
                 for use, net in nets.items()}
         assert all(torch.equal(outs[True][k], outs[False][0]) for k in range(3)), seed
+
+
+MIXED_TOL = 1e-4    # px: the mixed plan's budget at 1080p, a tenth of north_star's tolerance
+
+
+def test_mixed_plan_stays_within_its_budget_at_1080p(gpu):
+    """cfg.precision='mixed' with the shipped plan (vfml/cfg.py DEFAULT_MIXED_PLAN): mean EPE <= 1e-4 px at
+    1920x1080 on three weight seeds and for T in {3, 5}.  Reference: the CPU oracle for seed 0 (both T); for seeds 1
+    and 2 the engine's own exact-f32 arithmetic (cfg.precision='f32', v_mfma_f32_32x32x2_f32 - itself within 3e-6 px
+    of the oracle: test_model_forward_matches_oracle and bench.py's cpu_baseline) - a full-size oracle field costs
+    40 s of CPU time."""
+    import numpy as np
+    from oracle import mof_oracle as mo
+    from vfml import build_network, get_cfg
+    from vfml.cfg import DEFAULT_MIXED_PLAN
+    from vfml.synth import synthetic_clip
+    from vfml.weights import seeded_state_dict
+    H, W = 1080, 1920
+    frames = synthetic_clip(5, H, W)
+    clip = torch.from_numpy(np.stack(frames)).cuda()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    worst = 0.0
+    for seed in (0, 1, 2):
+        sd = seeded_state_dict(get_cfg(), seed)
+        nets = {}
+        for prec in ("mixed", "f32"):
+            c = get_cfg()
+            c.precision = prec
+            if prec == "mixed":
+                c.mfma_plan = dict(DEFAULT_MIXED_PLAN)
+            n = build_network(c)
+            n.load_state_dict(sd)
+            nets[prec] = n.cuda().eval()
+        for T in (3, 5):
+            win = clip[1:4] if T == 3 else clip
+            got = nets["mixed"].forward_u8(win, return_lowres=False)[0]
+            got = got[0, got.shape[1] // 2].permute(1, 2, 0).cpu()
+            if seed == 0:
+                ora = mo.build_network(mo.get_cfg()).eval()
+                ora.load_state_dict(sd)
+                x = (win.cpu().float() / 255.0).permute(0, 3, 1, 2)[None]
+                ref = ora(x, {})[0]
+                ref = ref[0, ref.shape[1] // 2].permute(1, 2, 0)
+                tag = "CPU oracle"
+            else:
+                ref = nets["f32"].forward_u8(win, return_lowres=False)[0]
+                ref = ref[0, ref.shape[1] // 2].permute(1, 2, 0).cpu()
+                tag = "exact-f32 engine"
+            e = (got - ref).pow(2).sum(-1).sqrt()
+            worst = max(worst, float(e.mean()))
+            print(f"mixed plan 1080p seed {seed} T={T}: mean EPE {float(e.mean()):.3e} px, max {float(e.max()):.3e} px vs {tag}")
+            assert float(e.mean()) <= MIXED_TOL, (seed, T, float(e.mean()))
+        for n in nets.values():
+            n.release_workspace()
+        del nets
+        torch.cuda.empty_cache()
+    print(f"mixed plan: worst mean EPE {worst:.3e} px (budget {MIXED_TOL:.0e})")

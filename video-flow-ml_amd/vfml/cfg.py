@@ -20,7 +20,21 @@ class Cfg:
 
 # precision='mixed' without an explicit plan: MFMAs per product by layer-name prefix (vfml/network.py `_nm`), chosen
 # with tools/precision_plan.py under an end-point-error budget (DESIGN.md "Mixed plan"); 3 where nothing matches.
-DEFAULT_MIXED_PLAN = {}
+DEFAULT_MIXED_PLAN = {
+    # layer-name prefix: terms of the split product (1 = both operands as plain f16).  Measured at 1080p, seq 5, one
+    # layer at a time against the all-3 field (tools/precision_plan.py, profiles/r02_precision_plan.md): these are the
+    # layers whose rounding barely reaches the flow - the two GRU [z | r] gate convolutions (sigmoid gates: 2.0e-5 /
+    # 3.5e-5 px), the correlation volume (both operands are activations: 3.1e-5 px), the flow branch of the motion
+    # encoder and the mask head (~1e-6 px each).  Everything that feeds the flow linearly (motion encoder output,
+    # q gates, flow head: 2e-4 .. 8e-4 px from the weights' rounding alone) stays at 3.
+    "update_block.gru.convzr1.iter": 1,
+    "update_block.gru.convzr2.iter": 1,
+    "corr": 1,
+    "update_block.encoder.convf1": 1,
+    "update_block.encoder.convf2": 1,
+    "update_block.mask.0": 1,
+    "update_block.mask.2": 1,
+}
 
 
 def get_cfg():

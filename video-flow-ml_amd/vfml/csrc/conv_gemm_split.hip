@@ -1118,25 +1118,27 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     a.nm = 3;       // (the general-loader GEMM form exists at full precision only: never less accurate than asked)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
   }
-  if constexpr (WM * WN == 4) {   // the shapes the dispatcher picks by itself
+  if constexpr (WM * WN == 4) {   // the shapes the dispatcher picks by itself: 16x16x32 MFMAs (MF16)
+    // VFML_MF32=1: the 32x32x16 shape for the full-precision uniform-step variants (A/B; MF16 is 9-12 % faster on the
+    // 1080p update-block shapes: the chip holds a higher clock on it)
+    static const int mf32 = getenv("VFML_MF32") ? atoi(getenv("VFML_MF32")) : 0;
     if constexpr (TM * TN >= 2) {
-      static const int mf16 = getenv("VFML_MF16") ? atoi(getenv("VFML_MF16")) : 0;
-      if (a.fastk && mf16 && a.nm == 3) return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
       if (a.fastk) {
-        if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2>(a, s);
-        if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, true, false, 4>(a, s);
-        if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, true, false, 1>(a, s);
-        return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
+        if (mf32 && a.nm == 3) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
+        if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2, true>(a, s);
+        if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, true, false, 4, true>(a, s);
+        if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, true, false, 1, true>(a, s);
+        return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
       }
     }
     a.fastk = 0; a.abias = 0;
-    if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, false, false, 2>(a, s);
-    if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, false, false, 4>(a, s);
-    if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, false, false, 1>(a, s);
-    return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
+    if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, false, false, 2, true>(a, s);
+    if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, false, false, 4, true>(a, s);
+    if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, false, false, 1, true>(a, s);
+    return launch_dma_k<TM, TN, WM, WN, false, false, false, 3, true>(a, s);
   }
   a.fastk = 0; a.abias = 0;
-  a.nm = 3;         // (8-wave experiment shapes: full precision only)
+  a.nm = 3;         // (8-wave experiment shapes: full precision, 32x32x16 only)
   return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
 }
 

@@ -205,11 +205,11 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
             if not fastk:
                 nm = 3
-            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}>"   # persistent GEMM form
+            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}, false>"   # persistent GEMM form
         if cout <= 32:
-            return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}>"
+            return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}, true>"
         if cout <= 64:
-            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, {nm}>"
+            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, {nm}, true>"
         def cost(tbm, tbn, mf, eff):
             tiles = -(-m // tbm) * -(-cout // tbn)
             return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
@@ -220,7 +220,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         for c, name in cands[1:]:
             if c < best:
                 best, t = c, name
-        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, {nm}>"
+        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, {nm}, true>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}, {nm}>"
 
