@@ -1081,6 +1081,201 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
+// ---- loader-wave variant of the convolution form ----------------------------------------------------------------
+// The kernel above lets every MFMA wave issue its share of the K step's LDS-DMA pieces between its MFMAs; a wave issues
+// in order and every piece (M0 move, address VALU, the texture-path hand-off) holds it 40-100 cycles during which its
+// matrix pipe slot goes to the other resident workgroup or to nobody.  Here the WM*WN MFMA waves never touch VMEM in the
+// K loop: a fifth wave of the workgroup owns ALL pieces of a step (TBM/8 + TBN/8), computes their offsets (uniform-step
+// loader: one scalar tap / channel offset per step), issues them into the stage the MFMA waves left one step ago,
+// waits for them (vmcnt) and meets the MFMA waves at ONE barrier per K step:
+//     loader:  issue(0) | wait, barrier_0, issue(1) | wait, barrier_1, issue(2) | ...
+//     MFMA  :           |       barrier_0, compute(0) |     barrier_1, compute(1) | ...
+// barrier_k orders (a) step k's data before its readers and (b) the readers of step k-1 before the refill of their stage.
+// Two stages, two workgroups per CU (10 waves: three on two of the SIMDs, hence the 168-register bound).
+// 16x16x32 MFMAs and the uniform-step loader only (every update-block convolution qualifies).
+template <int TM, int TN, int WM, int WN, int NM>
+__global__ __launch_bounds__((WM * WN + 1) * 64, 3) void conv_gemm_lw_kernel(const SplitArgs a) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
+  constexpr int APT = TBM / 8, BPT = TBN / 8;
+  constexpr int ASZ = TBM * 128, BSZ = TBN * 128, STG = ASZ + BSZ;
+  constexpr int LDC = TBN + 4;
+  constexpr bool BHI = NM == 2 || NM == 1, AHI = NM == 4 || NM == 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sC = reinterpret_cast<float*>(smem_raw);
+
+  const int total = a.mtiles * a.ntiles;
+  int tile;
+  {
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
+    const int q = total >> 3, r = total & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lw;
+  }
+  const int nt = tile % a.ntiles, mt = tile / a.ntiles;
+  const int m0 = mt * TBM, n0 = nt * TBN;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nk = a.Kp / BK;
+
+  if (wave == NW) {
+    // ------------------------------------------------------------------------------------------- the loader
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(const_cast<float*>(a.in0)) - a.abias, 0, a.bytes0 + a.abias, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
+    // piece pc covers tile rows 8 pc .. 8 pc + 7; lane -> (row lane >> 3, slot lane & 7); the slot holds logical piece
+    // slot ^ swz16((row >> 1) & 7), (row >> 1) & 7 = (4 pc + (lane >> 4)) & 7: two cases, pc even / odd
+    const int pce = (lane & 7) ^ swz16((lane >> 4) & 7), pco = (lane & 7) ^ swz16((4 + (lane >> 4)) & 7);
+    int rpa[APT];
+    unsigned tapbad[APT];          // bit (ky * kw + kx) set: that tap of the row lies outside the image (or row >= M)
+#pragma unroll
+    for (int pc = 0; pc < APT; ++pc) {
+      const int piece = (pc & 1) ? pco : pce;
+      const int kg = piece >> 1, hl = piece & 1;
+      const int m = m0 + 8 * pc + (lane >> 3);
+      unsigned ok = 0u;
+      int off = 0;
+      if (a.pointwise) {
+        if (m < a.M) {
+          ok = 1u;
+          off = (m * a.ld0 + a.d0off) * 4;
+        }
+      } else if (m < a.M) {
+        const int hw = a.ho * a.wo;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int oy = rem / a.wo;
+        const int ox = rem - oy * a.wo;
+        const int iy0 = oy * a.stride - a.pad_h, ix0 = ox * a.stride - a.pad_w;
+        off = (((n * a.H + iy0) * a.W + ix0) * a.ld0 + a.d0off) * 4;
+        for (int ky = 0; ky < a.kh; ++ky)
+          for (int kx = 0; kx < a.kw; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W) ok |= 1u << (ky * a.kw + kx);
+      }
+      rpa[pc] = off + a.abias + kg * 32 + hl * 16;
+      if (AHI && hl) rpa[pc] |= (int)0x80000000;          // lo slots of the activations: never fetched
+      tapbad[pc] = ~ok;
+    }
+    int cbs[BPT];
+#pragma unroll
+    for (int pc = 0; pc < BPT; ++pc) {
+      const int piece = (pc & 1) ? pco : pce;
+      const int kg = piece >> 1, hl = piece & 1;
+      const int col = n0 + 8 * pc + (lane >> 3);
+      cbs[pc] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : 0x40000000;
+    }
+    int scb = 0, sky = 0, skx = 0;
+    auto issue_step = [&](int k) {
+      char* stage = smem_raw + (k & 1) * STG;
+      const int cl = scb < a.c0 ? scb : scb - a.c0;
+      const int soffA = ((sky * a.W + skx) * a.ld0 + cl) * 4 + (scb < a.c0 ? 0 : a.src1_delta);
+      const unsigned stap = sky * a.kw + skx;
+      const int past = scb >= a.ctot ? (int)0x80000000 : 0;
+      const int soffB = k * (BK * 2);
+#pragma unroll
+      for (int pc = 0; pc < APT; ++pc) {
+        const int bad = __builtin_amdgcn_sbfe((int)tapbad[pc], stap, 1u);     // -1: outside
+        dma16(r0, (bad & (int)0x80000000) | past | rpa[pc], soffA, stage + pc * 1024);
+      }
+#pragma unroll
+      for (int pc = 0; pc < BPT; ++pc) dma16(rb, cbs[pc], soffB, stage + ASZ + pc * 1024);
+      if (++skx == a.kw) {
+        skx = 0;
+        if (++sky == a.kh) {
+          sky = 0;
+          scb += BK;
+        }
+      }
+    };
+    issue_step(0);
+    for (int k = 0; k < nk; ++k) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (k + 1 < nk) issue_step(k + 1);
+    }
+    // the epilogue's barriers (two per slab)
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- the MFMA waves
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+  const int r4 = lane & 15, u4 = lane >> 4;
+  const int p16 = ((2 * u4) ^ swz16((r4 >> 1) & 7)) * 16;
+  const int aoff4 = (wm * (32 * TM) + r4) * 128 + p16;
+  const int boff4 = ASZ + (wn * (32 * TN) + r4) * 128 + p16;
+  f32x4 acc4[2 * TM][2 * TN];
+  static_for<2 * TM>([&](auto ic) {
+    static_for<2 * TN>([&](auto jc) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc4[decltype(ic)::value][decltype(jc)::value][e] = 0.f;
+    });
+  });
+  for (int k = 0; k < nk; ++k) {
+    __builtin_amdgcn_s_barrier();
+    const char* base = smem_raw + (k & 1) * STG;
+    h16x8 bh[2 * TN], bl[2 * TN];
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
+      bh[j] = *reinterpret_cast<const h16x8*>(base + boff4 + j * 2048);
+      if constexpr (!BHI) bl[j] = *reinterpret_cast<const h16x8*>(base + (boff4 ^ 16) + j * 2048);
+    }
+    static_for<2 * TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      h16x8 ah, al;
+      ah = *reinterpret_cast<const h16x8*>(base + aoff4 + i * 2048);
+      if constexpr (!AHI) al = *reinterpret_cast<const h16x8*>(base + (aoff4 ^ 16) + i * 2048);
+      static_for<2 * TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc4[i][j], 0, 0, 0);
+        if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc4[i][j], 0, 0, 0);
+        if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc4[i][j], 0, 0, 0);
+      });
+    });
+  }
+  // epilogue in TM slabs, as in the kernel above
+  static_for<TM>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    __builtin_amdgcn_s_barrier();       // every wave is done with the stage buffers / with the previous slab
+    static_for<2>([&](auto tc) {
+      constexpr int t2 = decltype(tc)::value;
+      static_for<2 * TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sC[(wm * 32 + t2 * 16 + 4 * u4 + e) * LDC + wn * (32 * TN) + j * 16 + r4] = acc4[2 * i + t2][j][e];
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_rows<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32);
+  });
+}
+
+template <int TM, int TN, int WM, int WN, int NM>
+int launch_lw_k(SplitArgs& a, hipStream_t s) {
+  constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
+  constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
+  constexpr size_t slab = (size_t)WM * 32 * (TBN + 4) * 4;
+  constexpr size_t lds = stage > slab ? stage : slab;
+  a.mtiles = (a.M + TBM - 1) / TBM;
+  a.ntiles = (a.cout + TBN - 1) / TBN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_lw_kernel<TM, TN, WM, WN, NM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_lw_kernel<TM, TN, WM, WN, NM>), dim3(a.mtiles * a.ntiles), dim3((WM * WN + 1) * 64), lds, s, a);
+  return vfml_check_launch("vfml_conv2d_split");
+}
+
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
@@ -1123,6 +1318,13 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     // 1080p update-block shapes: the chip holds a higher clock on it)
     static const int mf32 = getenv("VFML_MF32") ? atoi(getenv("VFML_MF32")) : 0;
     if constexpr (TM * TN >= 2) {
+      static const int lwave = getenv("VFML_LW") ? atoi(getenv("VFML_LW")) : 0;   // experiment: the loader-wave kernel
+      if (a.fastk && lwave) {
+        if (a.nm == 2) return launch_lw_k<TM, TN, WM, WN, 2>(a, s);
+        if (a.nm == 4) return launch_lw_k<TM, TN, WM, WN, 4>(a, s);
+        if (a.nm == 1) return launch_lw_k<TM, TN, WM, WN, 1>(a, s);
+        return launch_lw_k<TM, TN, WM, WN, 3>(a, s);
+      }
       if (a.fastk) {
         if (mf32 && a.nm == 3) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
         if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2, true>(a, s);
