@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 16
+#define VFML_ABI_VERSION 17
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -77,18 +77,21 @@ typedef struct vfml_conv_desc {
                                                        pair (a, b) read the other way round is the volume of
                                                        (b, a): one pass of MFMAs, two stores             */
   int32_t flags;                                    /* VFML_CONV_* bits (vfml_conv2d_split)               */
-  double* stats_part;                               /* optional (vfml_conv2d_split, f32 sources): per 128-pixel row
-                                                       tile and output channel, the sum and the sum of squares
-                                                       of the stored result, [n][ceil(hw/128)][cout][2] doubles
-                                                       (hw = output pixels per image; n == 1 or hw % 128 == 0):
-                                                       the first pass of vfml_instnorm_stats done where the tile
-                                                       still is in LDS; fold with vfml_instnorm_finalize      */
+  double* stats_part;                               /* optional (vfml_conv2d_split, plain f32 output): per block of G
+                                                       consecutive output pixels and output channel, the sum and
+                                                       the sum of squares of the stored result,
+                                                       [n][ceil(hw/G)][cout][2] doubles (hw = output pixels per
+                                                       image; n == 1 or hw % G == 0; G = 128 with f32 sources,
+                                                       32 with split-row sources - VFML_STATS_ROWS_*): the first
+                                                       pass of vfml_instnorm_stats done where the tile still is
+                                                       in LDS; fold with vfml_instnorm_finalize               */
 } vfml_conv_desc;
 
 /* flags: accumulate the two cross terms of the split product in the order (a_lo*b_hi, a_hi*b_lo) instead of
  * (a_hi*b_lo, a_lo*b_hi).  out[q][s] of a call with operands (A, B) and out[s][q] of the call with operands
  * (B, A) and this flag are then the same sequence of f32 additions, i.e. bit-identical - which makes a
  * correlation volume computed directly equal to the one obtained as another call's out_t. */
+enum { VFML_STATS_ROWS_F32 = 128, VFML_STATS_ROWS_S16 = 32 };
 enum { VFML_CONV_SWAP_CROSS = 1,
 /* Fewer MFMAs per product, per call (the per-layer precision plan of the network, cfg.precision):
  *   VFML_CONV_MFMA2  the weight operand as ONE f16 (its hi plane; hi is the round-to-nearest f16 of the weight, so the
@@ -182,9 +185,12 @@ int vfml_instnorm_stats(const float* x, int n, int hw, int c, float eps,
                         float* stats, void* workspace, void* stream);
 /* out = relu( norm(x; stats) )                                  if res == NULL
  * out = relu( res' + relu(norm(x; stats)) )                     otherwise, where
- *       res' = res (res_stats == NULL) or norm(res; res_stats)  (down-sampled shortcut).   */
+ *       res' = res (res_stats == NULL) or norm(res; res_stats)  (down-sampled shortcut).
+ * out_fmt VFML_FMT_S16: out - and a res without res_stats, which is an earlier out - are split rows (c % 8 == 0): the
+ * operand format of the LDS-DMA convolution kernel that consumes them; x (a convolution's raw result) and a res with
+ * res_stats stay f32. */
 int vfml_instnorm_apply(const float* x, const float* stats, const float* res,
-                        const float* res_stats, int n, int hw, int c, float* out, void* stream);
+                        const float* res_stats, int n, int hw, int c, float* out, int out_fmt, void* stream);
 
 /* 2x2/stride-2 average pooling (floor) of an NHWC map; used to build the pooled target-feature
  * pyramid so that pyramid level l of the correlation volume is one GEMM against level-l

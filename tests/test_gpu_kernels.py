@@ -491,13 +491,28 @@ def test_instnorm(gpu, c, hw):
     assert rel_err(from_nhwc(out, n, hw, 1, c), F.relu(res + y)) < 3e-6
     hip.instnorm_apply(xd, st, n, hw, c, out, res=rd, res_stats=st2)
     assert rel_err(from_nhwc(out, n, hw, 1, c), F.relu(F.instance_norm(res) + y)) < 3e-6
+    # split-row results (and split-row residual): what the encoder's LDS-DMA convolutions read
+    o16 = torch.zeros_like(xd)
+    dec = lambda t: s16_decode(t, n * hw, c, c).view(n, hw, 1, c).permute(0, 3, 1, 2)
+    hip.instnorm_apply(xd, st, n, hw, c, o16, out_fmt=hip.FMT_S16)
+    assert rel_err(dec(o16), y) < 3e-6
+    r16 = torch.empty_like(xd)
+    hip.to_s16(rd, n * hw, c, c, r16, c)
+    hip.instnorm_apply(xd, st, n, hw, c, o16, res=r16, out_fmt=hip.FMT_S16)
+    assert rel_err(dec(o16), F.relu(res + y)) < 3e-6
+    hip.instnorm_apply(xd, st, n, hw, c, o16, res=rd, res_stats=st2, out_fmt=hip.FMT_S16)
+    assert rel_err(dec(o16), F.relu(F.instance_norm(res) + y)) < 3e-6
 
 
+@pytest.mark.parametrize("src16", [False, True])
 @pytest.mark.parametrize("n,cin,cout,k,stride,H,W", [(1, 64, 64, 3, 1, 37, 53), (1, 4, 64, 7, 2, 70, 90), (1, 64, 96, 3, 2, 61, 45),
-                                                     (2, 96, 96, 3, 1, 16, 24), (1, 64, 96, 1, 2, 50, 38), (3, 128, 128, 3, 1, 8, 16)])
-def test_conv_leaves_instnorm_partials(gpu, n, cin, cout, k, stride, H, W):
+                                                     (2, 96, 96, 3, 1, 16, 24), (1, 64, 96, 1, 2, 50, 38), (3, 128, 128, 3, 1, 8, 16),
+                                                     (1, 128, 256, 1, 1, 33, 41), (1, 96, 128, 3, 2, 270, 480)])
+def test_conv_leaves_instnorm_partials(gpu, n, cin, cout, k, stride, H, W, src16):
     """conv2d(stats_part=...) + instnorm_finalize == conv2d + instnorm_stats on the stored result (the encoder's
-    fused path): ragged last row tile, column tiles that end inside a tile, several images with whole tiles each."""
+    fused path): ragged last row tile, column tiles that end inside a tile, several images with whole tiles each;
+    f32 sources (the register-staged kernel, blocks of 128 pixels) and split-row sources (the LDS-DMA kernel: blocks
+    of 32 pixels, every tile shape the dispatcher picks for these sizes)."""
     from vfml import hip
     g = torch.Generator().manual_seed(n * 1000 + cout + k)
     x = torch.randn(n, cin, H, W, generator=g)
@@ -506,15 +521,25 @@ def test_conv_leaves_instnorm_partials(gpu, n, cin, cout, k, stride, H, W):
     pad = k // 2
     ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     hw = ho * wo
-    wobj = as_weight(wt.permute(0, 2, 3, 1).reshape(-1).to(gpu), cout, "f16x3")
+    if src16 and cin < 32:
+        pytest.skip("split-row sources have at least 32 channels")
+    from vfml.weights import pack_conv_weight
+    wobj = as_weight(pack_conv_weight(wt, cblock=src16), cout, "f16x3", order=int(src16))
     out_a = torch.empty(n * hw * cout, device=gpu)
     out_b = torch.empty_like(out_a)
-    chunks = (hw + 127) // 128
+    rows = hip.STATS_ROWS_S16 if src16 else hip.STATS_ROWS_F32
+    chunks = (hw + rows - 1) // rows
     part = torch.full((n * chunks * cout * 2 + 8,), float("nan"), device=gpu, dtype=torch.float64)
     xd = nhwc(x)
+    fmt = hip.FMT_F32
+    if src16:
+        x16 = torch.empty_like(xd)
+        hip.to_s16(xd, n * H * W, cin, cin, x16, cin)
+        xd, fmt = x16, hip.FMT_S16
     hip.conv2d(xd, cin, cin, n, H, W, wobj, b.to(gpu), cout, k, k, out_a, cout, stride=stride, pad_h=pad, pad_w=pad,
-               stats_part=part)
-    hip.conv2d(xd, cin, cin, n, H, W, wobj, b.to(gpu), cout, k, k, out_b, cout, stride=stride, pad_h=pad, pad_w=pad)
+               stats_part=part, in_fmt=fmt)
+    hip.conv2d(xd, cin, cin, n, H, W, wobj, b.to(gpu), cout, k, k, out_b, cout, stride=stride, pad_h=pad, pad_w=pad,
+               in_fmt=fmt)
     assert torch.equal(out_a, out_b)
     assert torch.isnan(part[n * chunks * cout * 2:]).all() and not torch.isnan(part[:n * chunks * cout * 2]).any()
     st_a = torch.empty(n * cout * 2, device=gpu)
@@ -535,7 +560,7 @@ def test_conv_stats_partials_reject_straddling_tiles(gpu):
     part = torch.empty(2 * 1 * 64 * 2, device=gpu, dtype=torch.float64)
     with pytest.raises(RuntimeError, match="straddle"):
         hip.conv2d(x, 64, 64, 2, 10, 10, wobj, None, 64, 3, 3, out, 64, pad_h=1, pad_w=1, stats_part=part)
-    with pytest.raises(RuntimeError, match="stats_part"):
+    with pytest.raises(RuntimeError, match="stats_part|vfml_conv2d"):
         hip.conv2d(x, 64, 64, 1, 10, 10, torch.zeros(64 * 9 * 64, device=gpu), None, 64, 3, 3, out, 64, pad_h=1, pad_w=1,
                    stats_part=part)
 

@@ -1074,6 +1074,28 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
         }
         __syncthreads();
         epilogue_rows<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
+        if (a.stats_part) {
+          // instance-norm statistics of the slab while it is in LDS (vfml_conv_desc.stats_part, split-row sources): the
+          // slab's rows wb*32 .. wb*32+31 are the 32 consecutive output pixels from cur_m0 + wb*32*TM + i*32 on; one
+          // thread per (block, channel) sums the STORED values (same expression as epilogue_rows) in doubles
+          for (int p = t; p < TBN * WM; p += NT) {
+            const int ch = p % TBN, wb = p / TBN;
+            const int g0 = cur_m0 + wb * (32 * TM) + i * 32;
+            if (cur_n0 + ch < a.cout && g0 < a.M) {
+              const float b = a.bias ? a.bias[cur_n0 + ch] : 0.f;
+              double s1 = 0.0, s2 = 0.0;
+              for (int rr = 0; rr < 32; ++rr) {
+                if (g0 + rr >= a.M) break;
+                const double v = (double)((sC[(wb * 32 + rr) * LDC + ch] * a.w_inv + b) * a.out_scale);
+                s1 += v;
+                s2 += v * v;
+              }
+              double* o = a.stats_part + ((int64_t)(g0 >> 5) * a.cout + cur_n0 + ch) * 2;
+              o[0] = s1;
+              o[1] = s2;
+            }
+          }
+        }
       }
     }
     if (!PERSIST || next >= tile_end) break;
@@ -1081,7 +1103,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
-// ---- loader-wave variant of the convolution form ----------------------------------------------------------------
+#ifdef VFML_EXPERIMENT_LW
+// ---- loader-wave variant of the convolution form (EXPERIMENT, not built by default) ------------------------------
+// Measured on the 1080p update-block shapes (profiles/r02_loader_wave.md): correct (the split-row kernel tests pass with
+// VFML_LW=1) and 30 % SLOWER than the kernel above (262 vs 377 TFLOP/s on the 1x5 gate convolution): one wave issues an
+// LDS-DMA piece per ~137 cycles, so the 40 pieces of a 192 x 128 step take 5500 cycles where the four MFMA waves issuing
+// ten each, in parallel, take ~1000.  A loader needs as many waves as the consumers it feeds (cf. the ring-gemm row of
+// MI355X_MICROARCH.md: 4 loader + 4 consumer waves), which the register budget of two workgroups per CU does not have.
 // The kernel above lets every MFMA wave issue its share of the K step's LDS-DMA pieces between its MFMAs; a wave issues
 // in order and every piece (M0 move, address VALU, the texture-path hand-off) holds it 40-100 cycles during which its
 // matrix pipe slot goes to the other resident workgroup or to nobody.  Here the WM*WN MFMA waves never touch VMEM in the
@@ -1276,6 +1304,8 @@ int launch_lw_k(SplitArgs& a, hipStream_t s) {
   return vfml_check_launch("vfml_conv2d_split");
 }
 
+#endif  // VFML_EXPERIMENT_LW
+
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
@@ -1318,6 +1348,7 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     // 1080p update-block shapes: the chip holds a higher clock on it)
     static const int mf32 = getenv("VFML_MF32") ? atoi(getenv("VFML_MF32")) : 0;
     if constexpr (TM * TN >= 2) {
+#ifdef VFML_EXPERIMENT_LW
       static const int lwave = getenv("VFML_LW") ? atoi(getenv("VFML_LW")) : 0;   // experiment: the loader-wave kernel
       if (a.fastk && lwave) {
         if (a.nm == 2) return launch_lw_k<TM, TN, WM, WN, 2>(a, s);
@@ -1325,6 +1356,7 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
         if (a.nm == 1) return launch_lw_k<TM, TN, WM, WN, 1>(a, s);
         return launch_lw_k<TM, TN, WM, WN, 3>(a, s);
       }
+#endif
       if (a.fastk) {
         if (mf32 && a.nm == 3) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
         if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2, true>(a, s);
@@ -1690,10 +1722,11 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                "vfml_conv2d_split: out_t / VFML_CONV_SWAP_CROSS need split-row sources");
   if (d->stats_part) {
     const int64_t hw_out = (int64_t)((d->h + 2 * d->pad_h - d->kh) / d->stride + 1) * ((d->w + 2 * d->pad_w - d->kw) / d->stride + 1);
-    VFML_REQUIRE(in_fmt == VFML_FMT_F32 && out_fmt == VFML_FMT_F32 && d->epilogue == VFML_EPI_NONE && !d->addend &&
-                 (d->n == 1 || hw_out % BM == 0) && (reinterpret_cast<uintptr_t>(d->stats_part) & 7u) == 0,
-                 "vfml_conv2d_split: stats_part needs f32 sources and output, no epilogue / addend, and row tiles that do "
-                 "not straddle images (n == 1 or output pixels per image %% 128 == 0)");
+    const int rows = in_fmt == VFML_FMT_S16 ? VFML_STATS_ROWS_S16 : VFML_STATS_ROWS_F32;
+    VFML_REQUIRE(out_fmt == VFML_FMT_F32 && d->epilogue == VFML_EPI_NONE && !d->addend &&
+                 (d->n == 1 || hw_out % rows == 0) && (reinterpret_cast<uintptr_t>(d->stats_part) & 7u) == 0,
+                 "vfml_conv2d_split: stats_part needs a plain f32 output, no epilogue / addend, and pixel blocks that do "
+                 "not straddle images (n == 1 or output pixels per image %% %d == 0)", rows);
   }
   VFML_REQUIRE(k_order == VFML_KORDER_TAP || (k_order == VFML_KORDER_CBLOCK && in_fmt == VFML_FMT_S16),
                "vfml_conv2d_split: bad k_order (channel-block order needs split-row sources)");
@@ -1835,7 +1868,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
       }
       static const int direct_min = getenv("VFML_DIRECT_MIN") ? atoi(getenv("VFML_DIRECT_MIN")) : 1024;
       a.direct = (d->epilogue == VFML_EPI_NONE || d->epilogue == VFML_EPI_RELU) && !d->addend && out_fmt == VFML_FMT_F32 &&
-                 d->cout >= direct_min && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&
+                 !d->stats_part && d->cout >= direct_min && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&
                  (!d->bias || vfml_aligned16(d->bias));
       if (d->flags & VFML_CONV_SWAP_CROSS) {
         VFML_REQUIRE(a.direct && a.fastk, "vfml_conv2d_split: VFML_CONV_SWAP_CROSS is implemented by the GEMM form only "

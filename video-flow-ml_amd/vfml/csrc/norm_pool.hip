@@ -131,7 +131,9 @@ __global__ __launch_bounds__(FINAL_THREADS) void instnorm_final_kernel(const dou
 }
 
 // ------------------------------------------------------------------ instance-norm apply
-template <int MODE>  // 0: relu(norm(x)); 1: relu(res + relu(norm(x))); 2: relu(norm(res) + relu(norm(x)))
+// S16: the result - and in MODE 1 the residual, which is an earlier result - are split rows (VFML_FMT_S16): the
+// quad g of a pixel sits in unit g / 2, hi halves at byte 8 (g & 1) of the 32-byte unit, lo halves 16 bytes further
+template <int MODE, bool S16>  // 0: relu(norm(x)); 1: relu(res + relu(norm(x))); 2: relu(norm(res) + relu(norm(x)))
 __global__ void instnorm_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ stats,
                                       const f32x4* __restrict__ res, const float* __restrict__ rstats, int hw, int c,
                                       int64_t total4, f32x4* __restrict__ out) {
@@ -145,8 +147,20 @@ __global__ void instnorm_apply_kernel(const f32x4* __restrict__ x, const float* 
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[e] - st[2 * e]) * st[2 * e + 1], 0.f);
+    const int64_t qoff = (i - g) * 16 + (g >> 1) * 32 + (g & 1) * 8;     // byte offset of the quad's hi halves (S16)
     if (MODE == 1) {
-      const f32x4 rv = res[i];
+      f32x4 rv;
+      if (S16) {
+        const char* u = reinterpret_cast<const char*>(res) + qoff;
+        const vfml_h16x2 h0 = *reinterpret_cast<const vfml_h16x2*>(u), h1 = *reinterpret_cast<const vfml_h16x2*>(u + 4);
+        const vfml_h16x2 l0 = *reinterpret_cast<const vfml_h16x2*>(u + 16), l1 = *reinterpret_cast<const vfml_h16x2*>(u + 20);
+        rv[0] = (float)h0[0] + (float)l0[0];
+        rv[1] = (float)h0[1] + (float)l0[1];
+        rv[2] = (float)h1[0] + (float)l1[0];
+        rv[3] = (float)h1[1] + (float)l1[1];
+      } else {
+        rv = res[i];
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(rv[e] + o[e], 0.f);
     } else if (MODE == 2) {
@@ -155,7 +169,19 @@ __global__ void instnorm_apply_kernel(const f32x4* __restrict__ x, const float* 
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf((rv[e] - rs[2 * e]) * rs[2 * e + 1] + o[e], 0.f);
     }
-    out[i] = o;
+    if (S16) {
+      vfml_h16x2 h0, h1, l0, l1;
+      vfml_split2(o[0], o[1], h0, l0);
+      vfml_split2(o[2], o[3], h1, l1);
+      char* u = reinterpret_cast<char*>(out) + qoff;
+      uint2 hv, lv;
+      hv.x = __builtin_bit_cast(unsigned, h0); hv.y = __builtin_bit_cast(unsigned, h1);
+      lv.x = __builtin_bit_cast(unsigned, l0); lv.y = __builtin_bit_cast(unsigned, l1);
+      *reinterpret_cast<uint2*>(u) = hv;
+      *reinterpret_cast<uint2*>(u + 16) = lv;
+    } else {
+      out[i] = o;
+    }
   }
 }
 
@@ -242,23 +268,29 @@ extern "C" int vfml_instnorm_finalize(const double* part, int n, int chunks, int
 }
 
 extern "C" int vfml_instnorm_apply(const float* x, const float* stats, const float* res, const float* res_stats, int n,
-                                   int hw, int c, float* out, void* stream) {
+                                   int hw, int c, float* out, int out_fmt, void* stream) {
   VFML_REQUIRE(x && stats && out, "vfml_instnorm_apply: null pointer");
   VFML_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 4 == 0, "vfml_instnorm_apply: bad n/hw/c");
+  VFML_REQUIRE(out_fmt == VFML_FMT_F32 || (out_fmt == VFML_FMT_S16 && c % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31u) == 0 &&
+                                            (!res || res_stats || (reinterpret_cast<uintptr_t>(res) & 31u) == 0)),
+               "vfml_instnorm_apply: split-row output needs c %% 8 == 0 and 32-byte aligned out (and res)");
   VFML_REQUIRE(!(res_stats && !res), "vfml_instnorm_apply: res_stats without res");
   VFML_REQUIRE(vfml_aligned16(x) && vfml_aligned16(out) && vfml_aligned16(res), "vfml_instnorm_apply: alignment");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t total4 = (int64_t)n * hw * (c / 4);
   const dim3 g(grid_for(total4, 256)), b(256);
-  if (!res)
-    hipLaunchKernelGGL(instnorm_apply_kernel<0>, g, b, 0, s, (const f32x4*)x, stats, nullptr, nullptr, hw, c, total4,
-                       (f32x4*)out);
-  else if (!res_stats)
-    hipLaunchKernelGGL(instnorm_apply_kernel<1>, g, b, 0, s, (const f32x4*)x, stats, (const f32x4*)res, nullptr, hw, c,
-                       total4, (f32x4*)out);
-  else
-    hipLaunchKernelGGL(instnorm_apply_kernel<2>, g, b, 0, s, (const f32x4*)x, stats, (const f32x4*)res, res_stats, hw,
-                       c, total4, (f32x4*)out);
+  const bool s16 = out_fmt == VFML_FMT_S16;
+#define VFML_APPLY(MODE, S16, R, RS)                                                                                      \
+  hipLaunchKernelGGL((instnorm_apply_kernel<MODE, S16>), g, b, 0, s, (const f32x4*)x, stats, (const f32x4*)(R), RS, hw, c, \
+                     total4, (f32x4*)out)
+  if (!res) {
+    if (s16) VFML_APPLY(0, true, nullptr, nullptr); else VFML_APPLY(0, false, nullptr, nullptr);
+  } else if (!res_stats) {
+    if (s16) VFML_APPLY(1, true, res, nullptr); else VFML_APPLY(1, false, res, nullptr);
+  } else {
+    if (s16) VFML_APPLY(2, true, res, res_stats); else VFML_APPLY(2, false, res, res_stats);
+  }
+#undef VFML_APPLY
   return vfml_check_launch("vfml_instnorm_apply");
 }
 

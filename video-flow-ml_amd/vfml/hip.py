@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("VFML_LIB") or os.path.join(_HERE, "libvfml_hip.so")  
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
 
+STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 KORDER_TAP, KORDER_CBLOCK = 0, 1   # K-axis order of split weight planes (include/vfml.h)
@@ -87,7 +88,7 @@ def lib():
     L.vfml_transpose_to_s16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]
     L.vfml_add_to_s16.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]
     L.vfml_instnorm_finalize.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
-    L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                    c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
@@ -106,7 +107,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 16:
+    if L.vfml_abi_version() != 17:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -357,9 +358,10 @@ def instnorm_finalize(part, n, chunks, c, hw, stats, eps=1e-5):
            "vfml_instnorm_finalize")
 
 
-def instnorm_apply(x, stats, n, hw, c, out, res=None, res_stats=None):
+def instnorm_apply(x, stats, n, hw, c, out, res=None, res_stats=None, out_fmt=FMT_F32):
+    """out_fmt FMT_S16: `out` (and a `res` without res_stats, an earlier out) are split rows."""
     _check(lib().vfml_instnorm_apply(_ptr(_dev(x)), _ptr(_dev(stats)), _ptr(res), _ptr(res_stats), n, hw, c,
-                                     _ptr(_dev(out)), _stream()), "vfml_instnorm_apply")
+                                     _ptr(_dev(out)), out_fmt, _stream()), "vfml_instnorm_apply")
 
 
 def avgpool2x2(x, n, h, w, c, out):

@@ -105,10 +105,12 @@ class MemFlowNetHIP(MOFNetHIP):
             w = leaf.weight.detach().to(device=device, dtype=torch.float32)
             b = leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous()
             if name.endswith(".encoder.convc1"):       # lookup block padded to whole units (zero weights)
-                cor_p = (cin + 7) // 8 * 8 if split else (cin + 3) // 4 * 4
+                cor_p = (cin + 31) // 32 * 32 if split else (cin + 3) // 4 * 4   # whole K steps: the uniform-step loader
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cor_p - cin))
             # update-block convolutions read split-row activations (all but convf1): channel-block K order
-            cb = split and name.startswith(ub + ".") and not name.endswith(".convf1")
+            cb = split and ((name.startswith(ub + ".") and not name.endswith(".convf1")) or
+                            (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
+                            name in ("fnet.conv2", "cnet.conv2"))
             if cb:
                 cblock_names.add(name)
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin in (2, 3) else None, cblock=cb), b)
@@ -183,7 +185,7 @@ class MemFlowNetHIP(MOFNetHIP):
             raise ValueError("the MemFlow path is built on the split-f16 kernels: cfg.precision must be 'f16x3'")
         split, AF = True, hip.FMT_S16
         cor = L * (2 * R + 1) ** 2
-        cor_p = (cor + 7) // 8 * 8 if split else (cor + 3) // 4 * 4
+        cor_p = (cor + 31) // 32 * 32 if split else (cor + 3) // 4 * 4
         ub = "update_block"
         gamma = self._gamma
 

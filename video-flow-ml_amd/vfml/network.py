@@ -30,6 +30,14 @@ from . import hip
 from .weights import conv_spec, corr_channel_subset, pack_conv_weight
 
 
+def cor_pad(cor, split):
+    """Channels of one direction's lookup block in the motion encoder's input: whole float4s (f32 path), or, in split
+    rows, a multiple of 16 - the two directions then make whole 32-channel K steps (324 -> 336, K = 672) and the 1x1
+    `convc1` takes the uniform-step loader of the LDS-DMA kernel (340 instead of 210 TFLOP/s on it at 1080p); the pad
+    channels are zero on both sides (the buffer is zero-filled once, the weights are zero there)."""
+    return (cor + 15) // 16 * 16 if split else (cor + 3) // 4 * 4
+
+
 def take_frames(src, idx):
     """src[idx] along dim 0 without a host->device index upload (a pageable H2D copy would make the
     host wait for all queued GPU work): a view when idx is a contiguous run, device-side copies otherwise."""
@@ -100,7 +108,7 @@ class MOFNetHIP(_Holder):
                 base = cin // 2
                 sel = torch.tensor(corr_channel_subset(self.cfg.corr_levels, self.cfg.corr_radius), device=device)
                 cor = sel.numel()
-                cor_p = (cor + 7) // 8 * 8 if split else (cor + 3) // 4 * 4
+                cor_p = cor_pad(cor, split)
                 wp = torch.zeros(cout, 2 * cor_p, 1, 1, device=device)
                 wp[:, :cor] = w[:, sel]
                 wp[:, cor_p:cor_p + cor] = w[:, base + sel]
@@ -109,8 +117,11 @@ class MOFNetHIP(_Holder):
                 # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
                 w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
             # update-block convolutions read split-row activations (all but convf1, whose input is the
-            # 4-channel f32 flow): their weights go in channel-block K order (include/vfml.h)
-            cb = split and name.startswith("update_block.") and not name.endswith(".convf1")
+            # 4-channel f32 flow), and so do the encoders behind their 4-channel stem: those weights go in
+            # channel-block K order (include/vfml.h)
+            cb = split and ((name.startswith("update_block.") and not name.endswith(".convf1")) or
+                            (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
+                            name in ("fnet.conv2", "cnet.conv2"))
             if cb:
                 cblock_names.add(name)
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None, cblock=cb),
@@ -261,35 +272,36 @@ class MOFNetHIP(_Holder):
             hip.instnorm_stats(t, n, hw, c, s, ws)
             return s
 
-        # split-f16 path: the convolution leaves per-tile sums behind (its tile is in LDS anyway) and only the fold
-        # remains; row tiles of 128 pixels must not straddle frames
+        # split-f16 path: activations are split rows (written by instnorm_apply, read by the LDS-DMA convolution
+        # kernel); every convolution leaves per-block sums of its raw result behind (its tile is in LDS anyway) and
+        # only the fold remains.  Blocks (128 output pixels after the f32-source stem, 32 after split-row sources)
+        # must not straddle frames.
         split_prec = self._split()
-        part_len = n * ((h2 * w2 + 127) // 128) * 128 * 2          # largest layer: half resolution
+        AF = hip.FMT_S16 if split_prec else hip.FMT_F32
+        part_len = n * ((h2 * w2 + 31) // 32) * 64 * 2            # largest layer: half resolution, 64 channels
         parts = self._buf("enc_part", 3 * part_len, dev, torch.float64) if split_prec else None
 
-        def fused(hw):
-            return split_prec and (n == 1 or hw % 128 == 0)
-
-        def conv_stats(src, c, hh_, ww_, name, planes, dst, slot, k, stride=1, pad=0):
+        def conv_stats(src, c, hh_, ww_, name, planes, dst, slot, k, stride=1, pad=0, src_fmt=hip.FMT_F32):
             wgt, b = P[name]
             nm = self._nm(name) if split_prec else 3
             ho_, wo_ = (hh_ + 2 * pad - k) // stride + 1, (ww_ + 2 * pad - k) // stride + 1
             hw = ho_ * wo_
-            if not fused(hw):
+            rows = hip.STATS_ROWS_S16 if src_fmt == hip.FMT_S16 else hip.STATS_ROWS_F32
+            if not (split_prec and (n == 1 or hw % rows == 0)):
                 hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
-                           mfma=nm)
+                           mfma=nm, in_fmt=src_fmt)
                 return stats_of(dst, hw, planes, slot)
-            chunks = (hw + 127) // 128
+            chunks = (hw + rows - 1) // rows
             part = parts[slot * part_len:]
             hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
-                       stats_part=part, mfma=nm)
+                       stats_part=part, mfma=nm, in_fmt=src_fmt)
             s = st[slot * n * 128 * 2:]
             hip.instnorm_finalize(part, n, chunks, planes, hw, s)
             return s
 
         s0 = conv_stats(x, 4, H, W, f"{prefix}.conv1", 64, raw, 0, 7, stride=2, pad=3)
         cur = act[0]
-        hip.instnorm_apply(raw, s0, n, h2 * w2, 64, cur)
+        hip.instnorm_apply(raw, s0, n, h2 * w2, 64, cur, out_fmt=AF)
         ch, hh, ww, ci = 64, h2, w2, 0
         for li, (planes, stride) in enumerate([(64, 1), (96, 2), (128, 2)], start=1):
             for bi in range(2):
@@ -298,19 +310,19 @@ class MOFNetHIP(_Holder):
                 name = f"{prefix}.layer{li}.{bi}"
                 y = act[(ci + 1) % 3]
                 nxt = act[(ci + 2) % 3]
-                s1 = conv_stats(cur, ch, hh, ww, f"{name}.conv1", planes, raw, 0, 3, stride=stv, pad=1)
-                hip.instnorm_apply(raw, s1, n, ho * wo, planes, y)
-                s2 = conv_stats(y, planes, ho, wo, f"{name}.conv2", planes, raw, 1, 3, pad=1)
+                s1 = conv_stats(cur, ch, hh, ww, f"{name}.conv1", planes, raw, 0, 3, stride=stv, pad=1, src_fmt=AF)
+                hip.instnorm_apply(raw, s1, n, ho * wo, planes, y, out_fmt=AF)
+                s2 = conv_stats(y, planes, ho, wo, f"{name}.conv2", planes, raw, 1, 3, pad=1, src_fmt=AF)
                 if stv != 1:
-                    s3 = conv_stats(cur, ch, hh, ww, f"{name}.downsample.0", planes, raw2, 2, 1, stride=stv)
-                    hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=raw2, res_stats=s3)
+                    s3 = conv_stats(cur, ch, hh, ww, f"{name}.downsample.0", planes, raw2, 2, 1, stride=stv, src_fmt=AF)
+                    hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=raw2, res_stats=s3, out_fmt=AF)
                 else:
-                    hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=cur)
+                    hip.instnorm_apply(raw, s2, n, ho * wo, planes, nxt, res=cur, out_fmt=AF)
                 cur, ci = nxt, (ci + 2) % 3
                 ch, hh, ww = planes, ho, wo
         wgt, b = P[f"{prefix}.conv2"]
         hip.conv2d(cur, 128, 128, n, hh, ww, wgt, b, 256, 1, 1, out, ldo, out_off=out_off, epilogue=epilogue,
-                   split=split, out_fmt=out_fmt, mfma=self._nm(f"{prefix}.conv2") if split_prec else 3)
+                   split=split, out_fmt=out_fmt, in_fmt=AF, mfma=self._nm(f"{prefix}.conv2") if split_prec else 3)
         return hh, ww
 
     # ------------------------------------------------------------------ forward
@@ -496,7 +508,7 @@ class MOFNetHIP(_Holder):
         win = (2 * R + 1) ** 2
         cor = L * win
         AF = hip.FMT_S16 if self._split() else hip.FMT_F32   # update-block activations
-        cor_p = (cor + 7) // 8 * 8 if AF == hip.FMT_S16 else (cor + 3) // 4 * 4   # per-direction channel block
+        cor_p = cor_pad(cor, AF == hip.FMT_S16)   # per-direction channel block
 
         with torch.cuda.device(dev):
             hl, wl = [h], [w]
