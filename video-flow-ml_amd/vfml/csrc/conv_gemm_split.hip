@@ -1371,8 +1371,10 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, false, false, 1, true>(a, s);
     return launch_dma_k<TM, TN, WM, WN, false, false, false, 3, true>(a, s);
   }
-  a.fastk = 0; a.abias = 0;
-  a.nm = 3;         // (8-wave experiment shapes: full precision, 32x32x16 only)
+  // 8-wave shapes (one workgroup per CU; VFML_DMA_TILE experiments): full precision only
+  a.nm = 3;
+  if (a.fastk) return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
+  a.abias = 0;
   return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
 }
 

@@ -109,8 +109,9 @@ class MemFlowNetHIP(MOFNetHIP):
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cor_p - cin))
             # update-block convolutions read split-row activations (all but convf1): channel-block K order
             cb = split and ((name.startswith(ub + ".") and not name.endswith(".convf1")) or
-                            (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
-                            name in ("fnet.conv2", "cnet.conv2"))
+                            (self._enc_split_rows() and (
+                                (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
+                                name in ("fnet.conv2", "cnet.conv2"))))
             if cb:
                 cblock_names.add(name)
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin in (2, 3) else None, cblock=cb), b)

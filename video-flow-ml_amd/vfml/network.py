@@ -120,8 +120,9 @@ class MOFNetHIP(_Holder):
             # 4-channel f32 flow), and so do the encoders behind their 4-channel stem: those weights go in
             # channel-block K order (include/vfml.h)
             cb = split and ((name.startswith("update_block.") and not name.endswith(".convf1")) or
-                            (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
-                            name in ("fnet.conv2", "cnet.conv2"))
+                            (self._enc_split_rows() and (
+                                (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
+                                name in ("fnet.conv2", "cnet.conv2"))))
             if cb:
                 cblock_names.add(name)
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None, cblock=cb),
@@ -170,6 +171,11 @@ class MOFNetHIP(_Holder):
         if p not in self.PRECISIONS:
             raise ValueError(f"cfg.precision must be one of {self.PRECISIONS}, got {p!r}")
         return p
+
+    def _enc_split_rows(self):
+        """Encoder activations as split rows (LDS-DMA convolutions) - the default; VFML_ENC_F32=1 keeps them f32 and
+        splits them while register-staged (round 1's path; A/B)."""
+        return not os.environ.get("VFML_ENC_F32")
 
     def _split(self):
         """Every arithmetic but 'f32' runs the split-f16 kernels on split-row activations; they differ in the
@@ -277,7 +283,7 @@ class MOFNetHIP(_Holder):
         # only the fold remains.  Blocks (128 output pixels after the f32-source stem, 32 after split-row sources)
         # must not straddle frames.
         split_prec = self._split()
-        AF = hip.FMT_S16 if split_prec else hip.FMT_F32
+        AF = hip.FMT_S16 if (split_prec and self._enc_split_rows()) else hip.FMT_F32
         part_len = n * ((h2 * w2 + 31) // 32) * 64 * 2            # largest layer: half resolution, 64 channels
         parts = self._buf("enc_part", 3 * part_len, dev, torch.float64) if split_prec else None
 
