@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 17
+#define VFML_ABI_VERSION 18
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -133,8 +133,9 @@ int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_l
  * outputs at least 1024 channels wide (cout % 4 == 0) take the persistent GEMM form of the kernel. */
 enum { VFML_KORDER_TAP = 0, VFML_KORDER_CBLOCK = 1 };
 
-/* f32 rows [rows][c] (row stride ld_src floats) -> split rows [rows][ld_dst] (VFML_FMT_S16); c % 4 == 0. */
-int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream);
+/* scale * f32 rows [rows][c] (row stride ld_src floats) -> split rows [rows][ld_dst] (VFML_FMT_S16); c % 4 == 0.
+ * (scale: a power of two keeps the split exact - the correlation GEMM's query rows carry x16.) */
+int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, float scale, void* stream);
 
 /* y = scale * src (f32 [rows][k], row stride ld floats) -> hi = f16(y), lo = f16(y - hi), each
  * [rows][kp], zero padded from k to kp (kp % 32 == 0).  A power-of-two scale that brings max|y|

@@ -1423,13 +1423,13 @@ __global__ void split_f16_kernel(const float* __restrict__ src, int64_t rows, in
 
 // f32 rows -> split rows, one quad (4 channels) per thread
 __global__ void to_s16_kernel(const float* __restrict__ src, int64_t rows, int c, int lds, float* __restrict__ dst,
-                              int ldd) {
+                              int ldd, float scale) {
   const int q4 = c / 4;
   const int64_t total = rows * q4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / q4;
     const int col = (int)(i - row * q4) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * lds + col);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * lds + col) * scale;
     U8 hi, lo;
     split4(v, hi, lo, 0);
     char* u = reinterpret_cast<char*>(dst + row * ldd + (col & ~7)) + (col & 4) * 2;
@@ -1684,7 +1684,8 @@ extern "C" int vfml_add_to_s16(const float* x, int64_t ldx, const float* aux, in
   return vfml_check_launch("vfml_add_to_s16");
 }
 
-extern "C" int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, void* stream) {
+extern "C" int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, float* dst, int ld_dst, float scale,
+                           void* stream) {
   VFML_REQUIRE(src && dst && rows > 0 && c > 0 && c % 4 == 0 && ld_src >= c && ld_src % 4 == 0 && ld_dst % 8 == 0 &&
                ld_dst >= ((c + 7) & ~7), "vfml_to_s16: bad shape (c %% 4, ld_src %% 4, ld_dst %% 8)");
   VFML_REQUIRE(vfml_aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0, "vfml_to_s16: alignment");
@@ -1692,7 +1693,7 @@ extern "C" int vfml_to_s16(const float* src, int64_t rows, int c, int ld_src, fl
   int64_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(to_s16_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, rows, c,
-                     ld_src, dst, ld_dst);
+                     ld_src, dst, ld_dst, scale);
   return vfml_check_launch("vfml_to_s16");
 }
 

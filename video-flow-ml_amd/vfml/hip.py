@@ -76,7 +76,7 @@ def lib():
     L.vfml_conv2d.argtypes = [POINTER(ConvDesc), c_void_p]
     L.vfml_conv2d_split.argtypes = [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int,
                                     c_void_p]
-    L.vfml_to_s16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]
+    L.vfml_to_s16.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_float, c_void_p]
     L.vfml_softmax_rows_s16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_float, c_void_p]
     L.vfml_transpose_split_f16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_split_f16.argtypes = [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]
@@ -107,7 +107,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 17:
+    if L.vfml_abi_version() != 18:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -404,10 +404,10 @@ def add_to_s16(x, ldx, aux, ld_aux, out, ld_out, rows, c, scale=1.0, x_off=0, au
                                  rows, c, float(scale), _stream()), "vfml_add_to_s16")
 
 
-def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0):
-    """f32 rows [rows][c] -> split rows (FMT_S16) at float offset dst_off of dst."""
-    _check(lib().vfml_to_s16(_ptr(_dev(src), src_off), rows, c, ld_src, _ptr(_dev(dst), dst_off), ld_dst, _stream()),
-           "vfml_to_s16")
+def to_s16(src, rows, c, ld_src, dst, ld_dst, src_off=0, dst_off=0, scale=1.0):
+    """scale * f32 rows [rows][c] -> split rows (FMT_S16) at float offset dst_off of dst."""
+    _check(lib().vfml_to_s16(_ptr(_dev(src), src_off), rows, c, ld_src, _ptr(_dev(dst), dst_off), ld_dst, float(scale),
+                             _stream()), "vfml_to_s16")
 
 
 def ptr_table_set(table, tensors):

@@ -173,9 +173,12 @@ class MOFNetHIP(_Holder):
         return p
 
     def _enc_split_rows(self):
-        """Encoder activations as split rows (LDS-DMA convolutions) - the default; VFML_ENC_F32=1 keeps them f32 and
-        splits them while register-staged (round 1's path; A/B)."""
-        return not os.environ.get("VFML_ENC_F32")
+        """Encoder activations as split rows through the LDS-DMA convolution kernel (VFML_ENC_S16=1), or f32 rows split
+        while register-staged (the default).  Measured A/B on one box at 1080p (profiles/r02_encoder_paths.md): the
+        split-row path is 0.25 ms per field SLOWER - the 64-channel layers at half resolution are bound by re-reading
+        every input pixel once per filter tap (1.2 GB of operand traffic per convolution against 46 us of MFMA work), in
+        either kernel; what they need is operand reuse across taps, not another staging path."""
+        return bool(os.environ.get("VFML_ENC_S16"))
 
     def _split(self):
         """Every arithmetic but 'f32' runs the split-f16 kernels on split-row activations; they differ in the
@@ -448,7 +451,7 @@ class MOFNetHIP(_Holder):
                     # side of a correlation GEMM (then <a, b> and <b, a> are the same products, and with
                     # VFML_CONV_SWAP_CROSS the same sums: a volume and its transpose are bit-identical)
                     fm16 = torch.empty(Pn * D, device=dev)
-                    hip.to_s16(fm * self.FMAP_ROW_SCALE, Pn, D, D, fm16, D)
+                    hip.to_s16(fm, Pn, D, D, fm16, D, scale=self.FMAP_ROW_SCALE)
                     fm = fm16
                 ent = (fm, tg)
                 out[j] = ent
