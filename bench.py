@@ -293,7 +293,7 @@ def main():
         split = "split" in name or "dma" in name      # the split-f16 kernels; the last template argument = MFMAs per product
         targs = [t.strip() for t in name[name.index("<") + 1:name.rindex(">")].split(",")]
         nm_arg = int(targs[7]) if "dma" in name else (int(targs[5]) if split else 1)    # the NM template argument
-        nm = {4: 2}.get(nm_arg, nm_arg)
+        nm = {4: 2, 5: 1}.get(nm_arg, nm_arg)
         peak = F16_MATRIX_PEAK_TFLOPS / nm if split else F32_MATRIX_PEAK_TFLOPS
         traffic, traffic_note = hbm_traffic_from_profiles(name, args.workload)
         result["roofline"] = {

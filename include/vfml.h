@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 18
+#define VFML_ABI_VERSION 19
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -131,7 +131,10 @@ int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_l
  * split-row source (GEMM rows) may span any number of bytes (the descriptor is rebased per tile); every other
  * source must span < 1 GiB, both sources of a two-source call must lie within 2 GiB of each other.  Plain f32
  * outputs at least 1024 channels wide (cout % 4 == 0) take the persistent GEMM form of the kernel. */
-enum { VFML_KORDER_TAP = 0, VFML_KORDER_CBLOCK = 1 };
+/*   VFML_KORDER_CBLOCK64 [cout][ci/64][ky][kx][ci%64]: the order of VFML_CONV_MFMA1 calls whose sources are whole 64-channel
+ *                       blocks (c0, c0+c1 multiples of 64; kp = K): the kernel then steps 64 channels of hi halves at a
+ *                       time (half the K steps and LDS-DMA instructions of the 32-channel steps, no lo half fetched). */
+enum { VFML_KORDER_TAP = 0, VFML_KORDER_CBLOCK = 1, VFML_KORDER_CBLOCK64 = 2 };
 
 /* scale * f32 rows [rows][c] (row stride ld_src floats) -> split rows [rows][ld_dst] (VFML_FMT_S16); c % 4 == 0.
  * (scale: a power of two keeps the split exact - the correlation GEMM's query rows carry x16.) */

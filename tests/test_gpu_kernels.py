@@ -792,3 +792,41 @@ def test_gemm_form_reduced_mfma_counts(gpu):
             rev = torch.zeros(S * ldt, device=gpu)
             hip.conv2d(y16, D, D, 1, 1, S, w1, None, P, 1, 1, rev, ldt, out_scale=1.0 / 16.0, in_fmt=hip.FMT_S16, mfma=1)
             assert torch.equal(rev.view(S, ldt)[:, :P].cpu(), got.t())
+
+
+@pytest.mark.parametrize("c0,c1,cout,kh,kw,stride", [(128, 0, 192, 3, 3, 1),     # 128 x 192 / 192 x 128 tiles
+                                                    (64, 128, 256, 1, 5, 1),    # two sources (the GRU gate shape)
+                                                    (64, 0, 64, 3, 3, 2),       # 128 x 64 tiles, strided
+                                                    (256, 0, 136, 1, 1, 1),     # 1x1: any weight order
+                                                    (192, 0, 128, 5, 1, 1)])    # three 64-channel blocks, vertical taps
+def test_conv2d_one_mfma_64_channel_steps(gpu, c0, c1, cout, kh, kw, stride):
+    """VFML_CONV_MFMA1 over whole 64-channel blocks: the kernel steps 64 channels of hi halves at a time (weights in
+    VFML_KORDER_CBLOCK64 order, or any order for 1x1).  Same numbers as the 32-channel-step kernel would give up to the
+    order of the f32 additions: both equal the float64 convolution of the f16-rounded operands."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(51 + c0 + kh)
+    n, H, W = 2, 19, 26
+    cin = c0 + c1
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout, generator=g)
+    ph, pw = kh // 2, kw // 2
+    order = hip.KORDER_TAP if kh * kw == 1 else hip.KORDER_CBLOCK64
+    w = as_weight(pack_conv_weight(wt, cblock=64 if order else False), cout, "f16x3", order=order)
+    emu = F.relu(F.conv2d(_f16(x), _f16(wt * w.scale) / w.scale, b.double(), stride=stride, padding=(ph, pw))).float()
+    ho, wo = emu.shape[-2:]
+    P = n * H * W
+    LD = cin + 64                                     # both sources as channel slices of one wider buffer
+    buf = torch.zeros(P * LD, device=gpu)
+    xs = nhwc(x).view(P, cin)
+    hip.to_s16(xs[:, :c0].contiguous().reshape(-1), P, c0, c0, buf, LD, dst_off=32)
+    if c1:
+        hip.to_s16(xs[:, c0:].contiguous().reshape(-1), P, c1, c1, buf, LD, dst_off=32 + c0)
+    out = torch.full((n * ho * wo * cout,), float("nan"), device=gpu)
+    hip.conv2d(buf, c0, LD, n, H, W, w, b.cuda(), cout, kh, kw, out, cout, stride=stride, pad_h=ph, pad_w=pw, in0_off=32,
+               in1=buf if c1 else None, c1=c1, ld1=LD if c1 else 0, in1_off=32 + c0, epilogue=hip.EPI_RELU,
+               in_fmt=hip.FMT_S16, mfma=1)
+    got = from_nhwc(out, n, ho, wo, cout)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, emu) < CONV_TOL["f16x3"], rel_err(got, emu)

@@ -580,8 +580,17 @@ __device__ __forceinline__ constexpr int swz16(int x) { return x ^ ((((x >> 1) ^
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
   static_assert(!(MF16 && (PERSIST || CSWAP)), "the 16x16x32 variant exists for the convolution form only");
-  constexpr bool BHI = NM == 2 || NM == 1;     // weight lo slots unused
-  constexpr bool AHI = NM == 4 || NM == 1;     // activation lo slots unused
+  // NM == 5 (H64): one MFMA per product like NM == 1, and a K step covers 64 channels of hi halves only: a staged row's 128
+  // bytes are the hi halves of eight 8-channel units (fetched at a 32-byte stride from the split-row source; the weight
+  // row's are contiguous in its hi plane) - no lane fetches a lo half, half the steps, barriers and LDS-DMA
+  // instructions of NM == 1 for the same MFMAs.  Uniform-step loader only, channel counts multiples of 64, weights in
+  // VFML_KORDER_CBLOCK64 order (or 1x1).  The image's swizzle is the plain one for both MFMA shapes (a fragment's two
+  // row groups differ by ONE piece here, not two: brute-force checked conflict-free).
+  constexpr bool H64 = NM == 5;
+  static_assert(!H64 || FASTK, "64-channel steps exist for the uniform-step loader only");
+  constexpr bool BHI = NM == 2 || NM == 1 || H64;     // weight lo slots unused
+  constexpr bool AHI = NM == 4 || NM == 1 || H64;     // activation lo slots unused
+  constexpr int KSTEP = H64 ? 64 : BK;               // channels per K step
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;   // workgroup tile
   constexpr int AP = TBM / (8 * NW), BP = TBN / (8 * NW);  // 1-KiB pieces (8 rows x 128 B) per wave per K step
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   // loader: piece j of this wave covers tile rows 8*NW*j + 8*wave .. +7; lane -> (row lane>>3, slot lane&7)
   const int lrow = 8 * wave + (lane >> 3);
   // slot ^ ((row >> 1) & 7)  (32x32x16 fragments), slot ^ swz16((row >> 1) & 7)  (16x16x32 fragments)
-  const int piece = (lane & 7) ^ (MF16 ? swz16((4 * wave + (lane >> 4)) & 7) : ((4 * wave + (lane >> 4)) & 7));
+  const int piece = (lane & 7) ^ (MF16 && !H64 ? swz16((4 * wave + (lane >> 4)) & 7) : ((4 * wave + (lane >> 4)) & 7));
   const int kg = piece >> 1, hl = piece & 1;
 
   int rp0[AP], rp1[AP];              // byte offsets of the row's first tap in source 0 / 1
@@ -687,16 +696,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       // that it is never negative (the descriptor base is shifted back); tapok holds the INVERTED tap mask
 #pragma unroll
       for (int j = 0; j < AP; ++j) {
-        rp0[j] += a.abias + kg * 32 + hl * 16;
+        rp0[j] += a.abias + (H64 ? piece * 32 : kg * 32 + hl * 16);
         tapok[j] = ~tapok[j];
-        if (AHI && hl) rp0[j] |= (int)0x80000000;      // lo slots of the activations: never fetched
+        if (AHI && !H64 && hl) rp0[j] |= (int)0x80000000;      // lo slots of the activations: never fetched
       }
       scb = sky = skx = 0;
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int col = n0 + 8 * NW * j + lrow;
-      colbase[j] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : (a.bhi ? 0x7ffffff0 : 0x40000000);
+      if constexpr (H64)
+        colbase[j] = col < a.cout ? a.whi_off + col * a.Kp * 2 + piece * 16 : (a.bhi ? 0x7ffffff0 : 0x40000000);
+      else
+        colbase[j] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : (a.bhi ? 0x7ffffff0 : 0x40000000);
     }
     if (a.tilebase) {
       // GEMM rows of a source that can exceed what one descriptor spans: base it at this tile's first row
@@ -713,7 +725,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   int va[AP];
   int soffA = 0, soffB = 0;      // scalar offsets of the step (buffer soffset operand)
   auto prep_step = [&](int k0) {
-    soffB = k0 * 2;
+    soffB = k0 * (H64 ? 4 : 2);          // k0 counts steps x 32: a 64-channel step is 128 bytes of the hi plane
     if constexpr (FASTK) {
       // every lane of the step reads the same tap of the same 32-channel block: the tap / channel / source
       // offset is one scalar, the per-piece work is "row valid for this tap?" -> two VALU instructions
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
         skx = 0;
         if (++sky == a.kh) {
           sky = 0;
-          scb += BK;
+          scb += KSTEP;
         }
       }
       return;
@@ -793,12 +805,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   const int r = lane & 31;
   const int half = lane >> 5;
   // fragment address of logical piece x at row r: row*128 + ((x ^ ((r>>1)&7)) * 16); x = 4*ks + 2*half + hl
-  const int q16 = ((((r >> 1) & 7) ^ (2 * half)) * 16);
+  const int q16 = ((((r >> 1) & 7) ^ (H64 ? half : 2 * half)) * 16);
   const int aoff = (wm * (32 * TM) + r) * 128 + q16;
   const int boff = ASZ + (wn * (32 * TN) + r) * 128 + q16;
   // 16x16x32: lane -> row lane & 15 of a 16-row tile, 8-channel unit lane >> 4 (hi piece 2u, lo piece 2u + 1)
   const int r4 = lane & 15, u4 = lane >> 4;
-  const int p16 = ((2 * u4) ^ swz16((r4 >> 1) & 7)) * 16;
+  const int p16 = (H64 ? (u4 ^ ((r4 >> 1) & 7)) : ((2 * u4) ^ swz16((r4 >> 1) & 7))) * 16;
   const int aoff4 = (wm * (32 * TM) + r4) * 128 + p16;
   const int boff4 = ASZ + (wn * (32 * TN) + r4) * 128 + p16;
 
@@ -810,35 +822,66 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   auto compute = [&](int stg, int lstg, bool issue) {
     const char* base = smem_raw + stg * STG;
     if constexpr (MF16) {
-      // one MFMA covers the step's 32 channels: 2*TN weight fragments stay in registers, the 2*TM activation tiles
-      // stream through; after each of the first half of the (i, j) groups one piece of the next step goes out
-      h16x8 bh[2 * TN], bl[2 * TN];
+      // one MFMA covers 32 channels of the step (H64: two of them cover its 64): 2*TN weight fragments stay in registers,
+      // the 2*TM activation tiles stream through; after each of the first half of the (i, j) groups one piece of the next
+      // step goes out
+      constexpr int KS = H64 ? 2 : 1;
+      static_for<KS>([&](auto sc) {
+        constexpr int ks = decltype(sc)::value;
+        h16x8 bh[2 * TN], bl[2 * TN];
 #pragma unroll
-      for (int j = 0; j < 2 * TN; ++j) {
-        bh[j] = *reinterpret_cast<const h16x8*>(base + boff4 + j * 2048);
-        if constexpr (!BHI) bl[j] = *reinterpret_cast<const h16x8*>(base + (boff4 ^ 16) + j * 2048);
-      }
-      static_for<2 * TM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        h16x8 ah, al;
-        ah = *reinterpret_cast<const h16x8*>(base + aoff4 + i * 2048);
-        if constexpr (!AHI) al = *reinterpret_cast<const h16x8*>(base + (aoff4 ^ 16) + i * 2048);
-        static_for<2 * TN>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc4[i][j], 0, 0, 0);
-          if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc4[i][j], 0, 0, 0);
-          if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc4[i][j], 0, 0, 0);
-          constexpr int GROUPS4 = 2 * TM * TN;          // the first half of the step's 4*TM*TN groups
-          constexpr int g = i * (2 * TN) + j;
-          constexpr int PER4 = (AP + BP + GROUPS4 - 1) / GROUPS4;
-          if constexpr (g < GROUPS4) {
-            if (issue) {
-              static_for<PER4>([&](auto qc) { issue_piece(lstg, g * PER4 + decltype(qc)::value); });
+        for (int j = 0; j < 2 * TN; ++j) {
+          bh[j] = *reinterpret_cast<const h16x8*>(base + (boff4 ^ (ks * 64)) + j * 2048);
+          if constexpr (!BHI) bl[j] = *reinterpret_cast<const h16x8*>(base + (boff4 ^ 16) + j * 2048);
+        }
+        static_for<2 * TM>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          h16x8 ah, al;
+          ah = *reinterpret_cast<const h16x8*>(base + (aoff4 ^ (ks * 64)) + i * 2048);
+          if constexpr (!AHI) al = *reinterpret_cast<const h16x8*>(base + (aoff4 ^ 16) + i * 2048);
+          static_for<2 * TN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc4[i][j], 0, 0, 0);
+            if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc4[i][j], 0, 0, 0);
+            if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc4[i][j], 0, 0, 0);
+            constexpr int GROUPS4 = KS * 2 * TM * TN;          // the first half of the step's groups
+            constexpr int g = (ks * 2 * TM + i) * (2 * TN) + j;
+            constexpr int PER4 = (AP + BP + GROUPS4 - 1) / GROUPS4;
+            if constexpr (g < GROUPS4) {
+              if (issue) {
+                static_for<PER4>([&](auto qc) { issue_piece(lstg, g * PER4 + decltype(qc)::value); });
+              }
             }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+          });
         });
       });
+      return;
+    }
+    if constexpr (H64) {
+      // 32x32x16, hi halves only: four 16-channel sub-steps per 64-channel step, logical piece 2 ks + half
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        h16x8 ah[TM], bh[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const h16x8*>(base + (aoff ^ (ks * 32)) + i * 4096);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const h16x8*>(base + (boff ^ (ks * 32)) + j * 4096);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            constexpr int GROUPS = 2 * TM * TN;     // the first half of the step's 4*TM*TN groups
+            const int g = (ks * TM + i) * TN + j;
+            constexpr int PER = (AP + BP + GROUPS - 1) / GROUPS;
+            if (issue && g < GROUPS) {
+#pragma unroll
+              for (int q = 0; q < PER; ++q) issue_piece(lstg, g * PER + q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
       return;
     }
 #pragma unroll
@@ -886,7 +929,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 
   // The step count is rounded up to even (one all-zero step when odd: out of range on the source side,
   // the weight side reads the next row's first step - multiplied by zeros).
-  const int nk = (a.Kp / BK + 1) & ~1;
+  const int nk = (a.Kp / KSTEP + 1) & ~1;
   constexpr int NSTORE = TM * TN * 4;                    // direct epilogue: 16-byte stores per thread, all issued
   constexpr int RELAXED = NSTORE < 63 ? NSTORE : 63;     // vmcnt that still covers the older DMAs
   constexpr int NSTORE_T = NSTORE + TM * TN * 4;         // with the transposed second output
@@ -1231,7 +1274,7 @@ __global__ __launch_bounds__((WM * WN + 1) * 64, 3) void conv_gemm_lw_kernel(con
   const int wm = wave / WN;
   const int wn = wave - wm * WN;
   const int r4 = lane & 15, u4 = lane >> 4;
-  const int p16 = ((2 * u4) ^ swz16((r4 >> 1) & 7)) * 16;
+  const int p16 = (H64 ? (u4 ^ ((r4 >> 1) & 7)) : ((2 * u4) ^ swz16((r4 >> 1) & 7))) * 16;
   const int aoff4 = (wm * (32 * TM) + r4) * 128 + p16;
   const int boff4 = ASZ + (wn * (32 * TN) + r4) * 128 + p16;
   f32x4 acc4[2 * TM][2 * TN];
@@ -1339,6 +1382,7 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
     if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
     if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
+    if (a.fastk && a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5>(a, s);
     if (a.nm == 2 && a.bhi) { vfml_set_error("vfml_conv2d_split: a weight operand without lo plane needs the uniform-step GEMM form"); return 1; }
     a.nm = 3;       // (the general-loader GEMM form exists at full precision only: never less accurate than asked)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);
@@ -1362,6 +1406,7 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
         if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2, true>(a, s);
         if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, true, false, 4, true>(a, s);
         if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, true, false, 1, true>(a, s);
+        if (a.nm == 5) return launch_dma_k<TM, TN, WM, WN, false, true, false, 5, true>(a, s);
         return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
       }
     }
@@ -1731,8 +1776,10 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                  "vfml_conv2d_split: stats_part needs a plain f32 output, no epilogue / addend, and pixel blocks that do "
                  "not straddle images (n == 1 or output pixels per image %% %d == 0)", rows);
   }
-  VFML_REQUIRE(k_order == VFML_KORDER_TAP || (k_order == VFML_KORDER_CBLOCK && in_fmt == VFML_FMT_S16),
-               "vfml_conv2d_split: bad k_order (channel-block order needs split-row sources)");
+  VFML_REQUIRE(k_order == VFML_KORDER_TAP || ((k_order == VFML_KORDER_CBLOCK || k_order == VFML_KORDER_CBLOCK64) && in_fmt == VFML_FMT_S16),
+               "vfml_conv2d_split: bad k_order (channel-block orders need split-row sources)");
+  VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || ((d->flags & VFML_CONV_MFMA1) && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0),
+               "vfml_conv2d_split: VFML_KORDER_CBLOCK64 is the weight order of VFML_CONV_MFMA1 calls over whole 64-channel blocks");
   VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
                (aux_fmt == VFML_FMT_F32 || aux_fmt == VFML_FMT_S16), "vfml_conv2d_split: bad format selector");
   const bool in16 = in_fmt == VFML_FMT_S16;
@@ -1766,6 +1813,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   if (k_order == VFML_KORDER_CBLOCK)
     VFML_REQUIRE(kp == d->kh * d->kw * ((d->c0 + d->c1 + BK - 1) / BK * BK),
                  "vfml_conv2d_split: kp=%d must be kh*kw*roundup32(c0+c1) in channel-block order", kp);
+  else if (k_order == VFML_KORDER_CBLOCK64)
+    VFML_REQUIRE(kp == K, "vfml_conv2d_split: kp=%d must be kh*kw*(c0+c1) in 64-channel-block order", kp);
   else
     VFML_REQUIRE(kp >= K && kp % BK == 0 && kp < K + BK, "vfml_conv2d_split: kp=%d must be K=%d rounded up to %d", kp, K, BK);
   const int ho = (d->h + 2 * d->pad_h - d->kh) / d->stride + 1;
@@ -1861,11 +1910,21 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         static const int no_fastk = getenv("VFML_NO_FASTK") ? atoi(getenv("VFML_NO_FASTK")) : 0;
         const int64_t abias = ((int64_t)d->pad_h * d->w + d->pad_w) * d->ld0 * 4;
         // (for a 1x1 convolution over whole 32-channel blocks the two K orders are the same bytes)
-        const bool cblock = k_order == VFML_KORDER_CBLOCK || (a.pointwise && (d->c0 + d->c1) % BK == 0);
+        const bool cblock = k_order == VFML_KORDER_CBLOCK || k_order == VFML_KORDER_CBLOCK64 ||
+                            (a.pointwise && (d->c0 + d->c1) % BK == 0);
         a.fastk = !no_fastk && cblock && d->c0 % BK == 0 && (d->c0 + d->c1) % BK == 0 &&
                   (!two || (d->ld1 == d->ld0 && a.d1off >= a.d0off)) && d->kh * d->kw <= 32 &&
                   (int64_t)a.bytes0 + abias < (1ll << 31);
+        VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || a.fastk,
+                     "vfml_conv2d_split: VFML_KORDER_CBLOCK64 needs the uniform-step loader (one row stride for both sources, kh*kw <= 32)");
         if (a.fastk) a.korder = VFML_KORDER_CBLOCK;
+        // one MFMA per product over whole 64-channel blocks: 64-channel steps of hi halves (NM 5) - for 1x1 kernels in
+        // any weight order (the K axis is the channel axis), else with the weights in 64-channel-block order
+        static const int no_h64 = getenv("VFML_NO_H64") ? atoi(getenv("VFML_NO_H64")) : 0;
+        if (a.nm == 1 && a.fastk && !no_h64 && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0 &&
+            (k_order == VFML_KORDER_CBLOCK64 || a.pointwise))
+          a.nm = 5;
+        VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || a.nm == 5, "vfml_conv2d_split: VFML_KORDER_CBLOCK64 weights need the 64-channel-step kernel (VFML_NO_H64 is set?)");
         a.abias = a.fastk ? (int)abias : 0;
         a.src1_delta = two ? (a.d1off - a.d0off) * 4 : 0;
       }

@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
-KORDER_TAP, KORDER_CBLOCK = 0, 1   # K-axis order of split weight planes (include/vfml.h)
+KORDER_TAP, KORDER_CBLOCK, KORDER_CBLOCK64 = 0, 1, 2   # K-axis order of split weight planes (include/vfml.h)
 CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1, CONV_MFMA2A = 1, 2, 4, 8   # vfml_conv_desc.flags
 
 
@@ -107,7 +107,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 18:
+    if L.vfml_abi_version() != 19:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -316,13 +316,15 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     plain = (epilogue in (EPI_NONE, EPI_RELU) and addend is None and out_fmt == FMT_F32 and ldo % 4 == 0)
     ctot = c0 + c1
     pointwise = kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0
-    fastk = (is_split and in_fmt == FMT_S16 and (weight.order == KORDER_CBLOCK or (pointwise and ctot % 32 == 0))
+    fastk = (is_split and in_fmt == FMT_S16 and (weight.order in (KORDER_CBLOCK, KORDER_CBLOCK64) or (pointwise and ctot % 32 == 0))
              and c0 % 32 == 0 and ctot % 32 == 0 and kh * kw <= 32 and not os.environ.get("VFML_NO_FASTK")
              and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
                                   weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
                                   ({3: 2, 2: 2, "2a": 1, 1: 1}[mfma] if (is_split and weight.lo is None)
-                                   else {"2a": 4}.get(mfma, mfma))),
+                                   else (5 if (mfma == 1 and fastk and c0 % 64 == 0 and ctot % 64 == 0 and
+                                               (weight.order == KORDER_CBLOCK64 or pointwise) and not os.environ.get("VFML_NO_H64"))
+                                         else {"2a": 4}.get(mfma, mfma)))),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)

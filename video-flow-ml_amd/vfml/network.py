@@ -93,11 +93,19 @@ class MOFNetHIP(_Holder):
     def _pack(self, device):
         """Repack every conv weight into the kernels' [cout][kh][kw][cin] order (once per load)."""
         split = self._split()
-        key = (str(device), split, tuple(p._version for p in self.parameters()),
+        key = (str(device), split, self._plan_key(), tuple(p._version for p in self.parameters()),
                tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is not None and self._packed_key == key:
             return self._packed
-        P, cblock_names = {}, set()
+        P, cblock_names, cb64_names = {}, set(), set()
+
+        def block_of(layer, c0, ctot):
+            """K-axis block of a split-row layer's weight planes: 64 channels where the layer runs one MFMA per product
+            over whole 64-channel blocks (the kernel then steps 64 channels of hi halves at a time), else 32."""
+            if split and self._nm(layer) == 1 and c0 % 64 == 0 and ctot % 64 == 0 and not os.environ.get("VFML_NO_H64"):
+                cb64_names.add(layer)
+                return 64
+            return True
         for name, cout, cin, kh, kw in self._spec:
             leaf = self._param(name)
             w = leaf.weight.detach().to(device=device, dtype=torch.float32)
@@ -125,6 +133,7 @@ class MOFNetHIP(_Holder):
                                 name in ("fnet.conv2", "cnet.conv2"))))
             if cb:
                 cblock_names.add(name)
+                cb = block_of(name, w.shape[1], w.shape[1])
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None, cblock=cb),
                        leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous())
         # GRU gates.  Input channels are [h | inp | motion | temporal]; `inp` (the context map) does not
@@ -143,8 +152,9 @@ class MOFNetHIP(_Holder):
             bq = raw["q"].bias.detach().to(device=device, dtype=torch.float32)
             for nm, wfull, bfull in ((f"update_block.gru.convzr{k}", wzr, bzr), (f"update_block.gru.convq{k}", wq, bq)):
                 it = torch.cat([wfull[:, :hid], wfull[:, 2 * hid:]], dim=1)
-                P[nm + ".iter"] = (pack_conv_weight(it, cblock=split), None)
-                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid], cblock=split), bfull.contiguous())
+                P[nm + ".iter"] = (pack_conv_weight(it, cblock=block_of(nm + ".iter", hid, it.shape[1]) if split else False), None)
+                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid], cblock=block_of(nm + ".ctx", hid, hid) if split else False),
+                                  bfull.contiguous())
                 if split:
                     cblock_names.update((nm + ".iter", nm + ".ctx"))
             for g in "zrq":
@@ -156,7 +166,8 @@ class MOFNetHIP(_Holder):
                     cout = self._cout_of[name] if name in self._cout_of else b.numel()
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
                     sw = hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc)
-                    sw.order = hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP
+                    sw.order = (hip.KORDER_CBLOCK64 if name in cb64_names else
+                                hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP)
                     P[name] = (sw, b)
         self._packed, self._packed_key = P, key
         self._graphs.clear()              # captured launches hold the old planes' addresses

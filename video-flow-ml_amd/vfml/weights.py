@@ -137,9 +137,10 @@ def pack_conv_weight(w, cin_pad=None, cblock=False):
     include/vfml.h VFML_KORDER_CBLOCK)."""
     cout, cin, kh, kw = w.shape
     if cblock:
-        cp = (cin + 31) // 32 * 32
+        blk = 64 if cblock == 64 else 32       # cblock=64: VFML_KORDER_CBLOCK64 (cin a multiple of 64)
+        cp = (cin + blk - 1) // blk * blk
         w = torch.nn.functional.pad(w.detach().to(torch.float32), (0, 0, 0, 0, 0, cp - cin))
-        return w.reshape(cout, cp // 32, 32, kh, kw).permute(0, 1, 3, 4, 2).contiguous().reshape(-1)
+        return w.reshape(cout, cp // blk, blk, kh, kw).permute(0, 1, 3, 4, 2).contiguous().reshape(-1)
     w = w.detach().to(torch.float32).permute(0, 2, 3, 1)
     if cin_pad is not None and cin_pad > cin:
         w = torch.nn.functional.pad(w, (0, cin_pad - cin))
