@@ -1410,6 +1410,10 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
         return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
       }
     }
+    if (a.nm == 5) {     // (cannot happen: the host picks 64-channel steps only where a uniform-step variant exists)
+      vfml_set_error("vfml_conv2d_split: no 64-channel-step variant for this tile shape");
+      return 1;
+    }
     a.fastk = 0; a.abias = 0;
     if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, false, false, 2, true>(a, s);
     if (a.nm == 4) return launch_dma_k<TM, TN, WM, WN, false, false, false, 4, true>(a, s);
@@ -1417,6 +1421,10 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     return launch_dma_k<TM, TN, WM, WN, false, false, false, 3, true>(a, s);
   }
   // 8-wave shapes (one workgroup per CU; VFML_DMA_TILE experiments): full precision only
+  if (a.nm == 5) {
+    vfml_set_error("vfml_conv2d_split: no 64-channel-step variant for the 8-wave experiment tiles");
+    return 1;
+  }
   a.nm = 3;
   if (a.fastk) return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
   a.abias = 0;
@@ -1778,8 +1786,9 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   }
   VFML_REQUIRE(k_order == VFML_KORDER_TAP || ((k_order == VFML_KORDER_CBLOCK || k_order == VFML_KORDER_CBLOCK64) && in_fmt == VFML_FMT_S16),
                "vfml_conv2d_split: bad k_order (channel-block orders need split-row sources)");
-  VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || ((d->flags & VFML_CONV_MFMA1) && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0),
-               "vfml_conv2d_split: VFML_KORDER_CBLOCK64 is the weight order of VFML_CONV_MFMA1 calls over whole 64-channel blocks");
+  VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || ((d->flags & VFML_CONV_MFMA1) && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0 && d->cout > 32),
+               "vfml_conv2d_split: VFML_KORDER_CBLOCK64 is the weight order of VFML_CONV_MFMA1 calls over whole 64-channel blocks "
+               "with more than 32 output channels");
   VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
                (aux_fmt == VFML_FMT_F32 || aux_fmt == VFML_FMT_S16), "vfml_conv2d_split: bad format selector");
   const bool in16 = in_fmt == VFML_FMT_S16;
@@ -1921,7 +1930,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         // one MFMA per product over whole 64-channel blocks: 64-channel steps of hi halves (NM 5) - for 1x1 kernels in
         // any weight order (the K axis is the channel axis), else with the weights in 64-channel-block order
         static const int no_h64 = getenv("VFML_NO_H64") ? atoi(getenv("VFML_NO_H64")) : 0;
-        if (a.nm == 1 && a.fastk && !no_h64 && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0 &&
+        // (cout > 32: the 128 x 32 tile of narrower outputs has no uniform-step instantiation)
+        if (a.nm == 1 && a.fastk && !no_h64 && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0 && d->cout > 32 &&
             (k_order == VFML_KORDER_CBLOCK64 || a.pointwise))
           a.nm = 5;
         VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || a.nm == 5, "vfml_conv2d_split: VFML_KORDER_CBLOCK64 weights need the 64-channel-step kernel (VFML_NO_H64 is set?)");

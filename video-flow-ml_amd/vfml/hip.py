@@ -322,7 +322,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
                                   weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
                                   ({3: 2, 2: 2, "2a": 1, 1: 1}[mfma] if (is_split and weight.lo is None)
-                                   else (5 if (mfma == 1 and fastk and c0 % 64 == 0 and ctot % 64 == 0 and
+                                   else (5 if (mfma == 1 and fastk and c0 % 64 == 0 and ctot % 64 == 0 and cout > 32 and
                                                (weight.order == KORDER_CBLOCK64 or pointwise) and not os.environ.get("VFML_NO_H64"))
                                          else {"2a": 4}.get(mfma, mfma)))),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,

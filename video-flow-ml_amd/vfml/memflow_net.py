@@ -227,7 +227,10 @@ class MemFlowNetHIP(MOFNetHIP):
 
             # memory read-out operator: attn = softmax(q k^T / sqrt(d)), P x P per pair, once per field
             P8 = (Pn + 7) // 8 * 8
-            ldA = (P8 + 31) // 32 * 32
+            # V as plain f16 in the read-out (one MFMA per product, 64-channel steps of hi halves: the kernel's NM 5) unless
+            # VFML_ATT_V_SPLIT=1 keeps its split rows (two MFMAs per product): row stride a multiple of 64 then
+            v_f16 = not os.environ.get("VFML_ATT_V_SPLIT")
+            ldA = (P8 + 63) // 64 * 64 if v_f16 else (P8 + 31) // 32 * 32
             qmap = self._buf("att_q", MP * AD, dev)
             kmap = self._buf("att_k", MP * AD, dev)
             wgt, b = P["query"]
@@ -297,7 +300,7 @@ class MemFlowNetHIP(MOFNetHIP):
                 for k in range(B if plain else 0):
                     hip.transpose_to_s16(val, Pn, AD, AD, vrows, ldA, scale=16.0, src_off=k * Pn * AD)
                     hip.conv2d(vrows, ldA, ldA, AD, 1, 1, attn[k], None, Pn, 1, 1, ro, ldA, out_scale=1.0 / 16.0,
-                               in_fmt=AF, out_t=ro_t, ld_out_t=AD)
+                               in_fmt=AF, out_t=ro_t, ld_out_t=AD, mfma=1 if v_f16 else 3)
                     hip.add_to_s16(ro_t, AD, G, GLD, G, GLD, Pn, AD, scale=gamma, aux_off=k * Pn * GLD + MF,
                                    out_off=k * Pn * GLD + MT)
                 for k in range(0 if plain else B):

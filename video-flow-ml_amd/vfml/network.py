@@ -99,10 +99,12 @@ class MOFNetHIP(_Holder):
             return self._packed
         P, cblock_names, cb64_names = {}, set(), set()
 
-        def block_of(layer, c0, ctot):
+        def block_of(layer, c0, ctot, cout):
             """K-axis block of a split-row layer's weight planes: 64 channels where the layer runs one MFMA per product
-            over whole 64-channel blocks (the kernel then steps 64 channels of hi halves at a time), else 32."""
-            if split and self._nm(layer) == 1 and c0 % 64 == 0 and ctot % 64 == 0 and not os.environ.get("VFML_NO_H64"):
+            over whole 64-channel blocks, more than 32 outputs wide (the kernel then steps 64 channels of hi halves at a
+            time: include/vfml.h VFML_KORDER_CBLOCK64), else 32."""
+            if (split and self._nm(layer) == 1 and c0 % 64 == 0 and ctot % 64 == 0 and cout > 32
+                    and not os.environ.get("VFML_NO_H64")):
                 cb64_names.add(layer)
                 return 64
             return True
@@ -133,7 +135,7 @@ class MOFNetHIP(_Holder):
                                 name in ("fnet.conv2", "cnet.conv2"))))
             if cb:
                 cblock_names.add(name)
-                cb = block_of(name, w.shape[1], w.shape[1])
+                cb = block_of(name, w.shape[1], w.shape[1], cout)
             P[name] = (pack_conv_weight(w, cin_pad=4 if cin == 3 else None, cblock=cb),
                        leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous())
         # GRU gates.  Input channels are [h | inp | motion | temporal]; `inp` (the context map) does not
@@ -152,8 +154,8 @@ class MOFNetHIP(_Holder):
             bq = raw["q"].bias.detach().to(device=device, dtype=torch.float32)
             for nm, wfull, bfull in ((f"update_block.gru.convzr{k}", wzr, bzr), (f"update_block.gru.convq{k}", wq, bq)):
                 it = torch.cat([wfull[:, :hid], wfull[:, 2 * hid:]], dim=1)
-                P[nm + ".iter"] = (pack_conv_weight(it, cblock=block_of(nm + ".iter", hid, it.shape[1]) if split else False), None)
-                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid], cblock=block_of(nm + ".ctx", hid, hid) if split else False),
+                P[nm + ".iter"] = (pack_conv_weight(it, cblock=block_of(nm + ".iter", hid, it.shape[1], it.shape[0]) if split else False), None)
+                P[nm + ".ctx"] = (pack_conv_weight(wfull[:, hid:2 * hid], cblock=block_of(nm + ".ctx", hid, hid, wfull.shape[0]) if split else False),
                                   bfull.contiguous())
                 if split:
                     cblock_names.update((nm + ".iter", nm + ".ctx"))
