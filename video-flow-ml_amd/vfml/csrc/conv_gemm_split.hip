@@ -844,7 +844,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc4[i][j], 0, 0, 0);
             if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc4[i][j], 0, 0, 0);
             if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc4[i][j], 0, 0, 0);
-            constexpr int GROUPS4 = KS * 2 * TM * TN;          // the first half of the step's groups
+#ifndef VFML_ISSUE_DIV
+#define VFML_ISSUE_DIV 2      // the next step's pieces go out behind the first 1/DIV of this step's MFMA groups
+#endif
+            constexpr int GROUPS4 = KS * 4 * TM * TN / VFML_ISSUE_DIV;
             constexpr int g = (ks * 2 * TM + i) * (2 * TN) + j;
             constexpr int PER4 = (AP + BP + GROUPS4 - 1) / GROUPS4;
             if constexpr (g < GROUPS4) {

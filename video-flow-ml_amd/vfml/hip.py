@@ -319,12 +319,14 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     fastk = (is_split and in_fmt == FMT_S16 and (weight.order in (KORDER_CBLOCK, KORDER_CBLOCK64) or (pointwise and ctot % 32 == 0))
              and c0 % 32 == 0 and ctot % 32 == 0 and kh * kw <= 32 and not os.environ.get("VFML_NO_FASTK")
              and (in1 is None or (ld1 == ld0 and in1.data_ptr() + 4 * in1_off >= in0.data_ptr() + 4 * in0_off)))
+    nm_eff = {"2a": 4}.get(mfma, mfma)
+    if (mfma == 1 and fastk and c0 % 64 == 0 and ctot % 64 == 0 and cout > 32 and
+            (weight.order == KORDER_CBLOCK64 or pointwise) and not os.environ.get("VFML_NO_H64")):
+        nm_eff = 5                                           # 64-channel steps of hi halves
+    elif is_split and weight.lo is None:
+        nm_eff = {3: 2, 2: 2, 4: 1, 1: 1}[nm_eff]            # a single weight plane has no lo half to use
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
-                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross,
-                                  ({3: 2, 2: 2, "2a": 1, 1: 1}[mfma] if (is_split and weight.lo is None)
-                                   else (5 if (mfma == 1 and fastk and c0 % 64 == 0 and ctot % 64 == 0 and cout > 32 and
-                                               (weight.order == KORDER_CBLOCK64 or pointwise) and not os.environ.get("VFML_NO_H64"))
-                                         else {"2a": 4}.get(mfma, mfma)))),
+                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross, nm_eff),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)

@@ -124,12 +124,13 @@ def _fields_in_order(proc, clip, frame_indices, before=None):
             yield k0 + j, flow
 
 
-def default_chunk(slot_floats, n_items, world):
-    """Items per chunk: one with a single rank (the D2H of a field then hides under the next field), two with
-    several (one collective per two fields of every rank; fewer when an item exceeds 64 MB)."""
-    if world == 1:
-        return 1
-    return int(max(1, min(2, (128 << 20) // max(1, 4 * slot_floats), n_items)))
+def default_chunk(slot_floats, n_items, world, batch=1):
+    """Items per chunk: with a single rank one field (its D2H then hides under the next field), with several ranks two
+    (one collective per two fields of every rank; one when an item exceeds 64 MB) - and never fewer than the processor
+    computes per pass of the engine (`batch`: eight triples of the tri-frame network, three MemFlow pairs), or the
+    chunking would undo the batching."""
+    k = 1 if world == 1 else max(1, min(2, (128 << 20) // max(1, 4 * slot_floats)))
+    return int(max(1, min(max(k, batch), n_items)))
 
 
 _BUFFERS = {}
@@ -177,7 +178,12 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     lo, hi = bounds[rank]
     mine = items[lo:hi]
     slot = max([item_numel(H, W, t) for t in tiles]) + sum(h * w * 2 for h, w in lshapes)
-    K = chunk or default_chunk(slot, max(counts) if counts else 1, world)
+    batch = 1
+    if whole and getattr(proc, "compute_optical_flow_resident_batch", None) is not None:
+        batch = getattr(proc, "TRI_BATCH", None) or getattr(proc, "PAIR_BATCH", 1)
+        if getattr(proc, "TRI_BATCH", None) and not getattr(getattr(getattr(proc, "core", None), "model", None), "tri_frame", False):
+            batch = 1                                       # (the multi-frame network takes one window per pass)
+    K = chunk or default_chunk(slot, max(counts) if counts else 1, world, batch)
     n_chunks = -(-max(counts) // K) if counts and max(counts) > 0 else 0
     dev = clip.device
     nb = min(2, n_chunks)
