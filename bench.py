@@ -225,6 +225,8 @@ def main():
     alt = None
     if alt_precision:
         core.cfg.precision, core.cfg.mfma_plan = alt_precision, None
+        core.model.clear_feature_cache()      # nothing of the first plan's cached frames / pyramids is of use to this one
+        torch.cuda.synchronize()
         base = Wm + K + Pn + En
         job(mine[base:base + Wm], collect=False)
         torch.cuda.synchronize()

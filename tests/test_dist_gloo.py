@@ -65,6 +65,9 @@ def _worker(rank, world, port, tile_mode, q, chunk=None, fed=False):
             out = np.stack([seen[k] for k in range(7)])
     else:
         clip = proc.upload_clip(_clip())
+        # (buffers + one collective of the job's shape up front, as bench.py does before its timed region)
+        assert run_sharded(proc, clip, range(clip.shape[0]), tile_mode=tile_mode, rank=rank, world=world, chunk=chunk,
+                           prepare_only=True) is None
         out = run_sharded(proc, clip, range(clip.shape[0]), tile_mode=tile_mode, rank=rank, world=world, chunk=chunk,
                           on_field=on_field if rank == 0 else None)
         if rank == 0:

@@ -830,3 +830,12 @@ def test_conv2d_one_mfma_64_channel_steps(gpu, c0, c1, cout, kh, kw, stride):
     got = from_nhwc(out, n, ho, wo, cout)
     assert torch.isfinite(got).all()
     assert rel_err(got, emu) < CONV_TOL["f16x3"], rel_err(got, emu)
+    if order == hip.KORDER_CBLOCK64 and c1 == 0:
+        # the 64-channel-block order belongs to one-MFMA calls more than 32 outputs wide: anything else is refused
+        with pytest.raises(RuntimeError, match="CBLOCK64"):
+            hip.conv2d(buf, c0, LD, n, H, W, w, b.cuda(), cout, kh, kw, out, cout, stride=stride, pad_h=ph, pad_w=pw,
+                       in0_off=32, in_fmt=hip.FMT_S16, mfma=3)
+        w4 = as_weight(pack_conv_weight(wt[:4], cblock=64), 4, "f16x3", order=order)
+        with pytest.raises(RuntimeError, match="CBLOCK64"):
+            hip.conv2d(buf, c0, LD, n, H, W, w4, None, 4, kh, kw, out, 4, stride=stride, pad_h=ph, pad_w=pw,
+                       in0_off=32, in_fmt=hip.FMT_S16, mfma=1)

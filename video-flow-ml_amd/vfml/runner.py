@@ -194,6 +194,12 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
             recv = [[_buffer(f"recv{i}.{r}", (K, slot), dev) for r in range(world)] for i in range(nb)]
         host = [_buffer(f"host{i}", (world, K, slot), dev, pinned=on_gpu) for i in range(nb)]
     if prepare_only:
+        if world > 1 and n_chunks:
+            # one collective of the job's shape now: the backend's peer-to-peer connections (RCCL sets them up on first
+            # use) and its staging are then in place before a timed job starts
+            torch.distributed.gather(send[0], recv[0] if rank == 0 else None, dst=0, group=group)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
         return None
     side = torch.cuda.Stream(device=dev) if on_gpu and rank == 0 else None
     seq = getattr(proc, "sequence_length", 1)
