@@ -579,7 +579,7 @@ __device__ __forceinline__ constexpr int swz16(int x) { return x ^ ((((x >> 1) ^
 
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
-  static_assert(!(MF16 && (PERSIST || CSWAP)), "the 16x16x32 variant exists for the convolution form only");
+  static_assert(!(MF16 && PERSIST && !FASTK), "the 16x16x32 GEMM form exists for the uniform-step loader only");
   // NM == 5 (H64): one MFMA per product like NM == 1, and a K step covers 64 channels of hi halves only: a staged row's 128
   // bytes are the hi halves of eight 8-channel units (fetched at a 32-byte stride from the split-row source; the weight
   // row's are contiguous in its hi plane) - no lane fetches a lo half, half the steps, barriers and LDS-DMA
@@ -1034,10 +1034,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       __syncthreads();                       // every wave is done reading stage 1
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        if constexpr (MF16) {
+          static_for<2>([&](auto tc) {
+            constexpr int t2 = decltype(tc)::value;
+            static_for<2 * TN>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v = 0.f;
+                static_for<TM>([&](auto ii) { if (decltype(ii)::value == i) v = acc4[2 * decltype(ii)::value + t2][j][e]; });
+                ws[(t2 * 16 + 4 * u4 + e) * WC + j * 16 + r4] = v;
+              }
+            });
+          });
+        } else {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) ws[((e & 3) + 8 * (e >> 2) + 4 * half) * WC + j * 32 + r] = acc[i][j][e];
+        }
         // (same wave, LDS operations complete in order: no barrier between the writes and the reads)
 #pragma unroll
         for (int p = 0; p < 32 / RPI; ++p) {
@@ -1059,6 +1074,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           // with the row index rotated by (column >> 1) - the 32 lanes of a store group (one row, 32
           // columns) then hit 32 different banks - and leaves as 16-byte runs along the rows: a store
           // instruction covers 8 rows of out_t x 128 contiguous bytes.
+          if constexpr (MF16) {
+            static_for<2>([&](auto tc) {
+              constexpr int t2 = decltype(tc)::value;
+              static_for<2 * TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float v = 0.f;
+                  static_for<TM>([&](auto ii) { if (decltype(ii)::value == i) v = acc4[2 * decltype(ii)::value + t2][j][e]; });
+                  const int row = t2 * 16 + 4 * u4 + e, col = j * 16 + r4;
+                  ws[col * 32 + ((row + (col >> 1)) & 31)] = v;
+                }
+              });
+            });
+          } else {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1066,6 +1096,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
               const int row = (e & 3) + 8 * (e >> 2) + 4 * half, col = j * 32 + r;
               ws[col * 32 + ((row + (col >> 1)) & 31)] = acc[i][j][e];
             }
+          }
           const int rows_t = cols_valid, cols_t = rows_valid;      // extent of the transposed tile
           float* tbase_t = a.out_t + (int64_t)cur_n0 * a.ld_out_t + cur_m0;
           const __amdgpu_buffer_rsrc_t rt =
@@ -1382,10 +1413,14 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
 template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
   if (a.direct) {   // (128 x 128: the one persistent tile shape that does not spill)
-    if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
-    if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
-    if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
-    if (a.fastk && a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5>(a, s);
+    // the uniform-step GEMM forms run 16x16x32 MFMAs too (VFML_MF32=1: the 32x32x16 shape for the full-precision ones)
+    static const int mf32g = getenv("VFML_MF32") ? atoi(getenv("VFML_MF32")) : 0;
+    if (a.cswap) return mf32g ? launch_dma_k<2, 2, 2, 2, true, true, true>(a, s)     // (host: cswap implies fastk and nm == 3)
+                              : launch_dma_k<2, 2, 2, 2, true, true, true, 3, true>(a, s);
+    if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2, true>(a, s);  // (host: bhi implies fastk, nm <= 2)
+    if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1, true>(a, s);
+    if (a.fastk && a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5, true>(a, s);
+    if (a.fastk && a.nm == 3 && !mf32g) return launch_dma_k<2, 2, 2, 2, true, true, false, 3, true>(a, s);
     if (a.nm == 2 && a.bhi) { vfml_set_error("vfml_conv2d_split: a weight operand without lo plane needs the uniform-step GEMM form"); return 1; }
     a.nm = 3;       // (the general-loader GEMM form exists at full precision only: never less accurate than asked)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);

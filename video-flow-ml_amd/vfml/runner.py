@@ -306,10 +306,15 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
         ev.synchronize()
         unpack(c, host[b])
 
+    import os
+    import time
+    trace = [] if os.environ.get("VFML_RUNNER_TIMING") else None     # host-side seconds per chunk: (enqueue, finish)
     prev = None
     for c in range(n_chunks):
         b = c % 2
+        t_a = time.perf_counter()
         compute_chunk(c, send[b])
+        t_b = time.perf_counter()
         work = ev_done = None
         if world > 1:
             work = torch.distributed.gather(send[b], recv[b] if rank == 0 else None, dst=0, group=group, async_op=True)
@@ -318,7 +323,12 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
             ev_done.record()
         if prev is not None:
             finish(*prev)
+        if trace is not None:
+            trace.append((t_b - t_a, time.perf_counter() - t_b))
         prev = (c, work, ev_done)
     if prev is not None:
         finish(*prev)
+    if trace is not None and rank == 0:
+        print("[runner] host ms per chunk (enqueue, finish previous): " +
+              " ".join(f"({1e3 * a:.1f},{1e3 * f:.1f})" for a, f in trace), flush=True)
     return out
