@@ -1413,14 +1413,23 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
 template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
   if (a.direct) {   // (128 x 128: the one persistent tile shape that does not spill)
-    // the uniform-step GEMM forms run 16x16x32 MFMAs too (VFML_MF32=1: the 32x32x16 shape for the full-precision ones)
-    static const int mf32g = getenv("VFML_MF32") ? atoi(getenv("VFML_MF32")) : 0;
-    if (a.cswap) return mf32g ? launch_dma_k<2, 2, 2, 2, true, true, true>(a, s)     // (host: cswap implies fastk and nm == 3)
-                              : launch_dma_k<2, 2, 2, 2, true, true, true, 3, true>(a, s);
-    if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2, true>(a, s);  // (host: bhi implies fastk, nm <= 2)
-    if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1, true>(a, s);
-    if (a.fastk && a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5, true>(a, s);
-    if (a.fastk && a.nm == 3 && !mf32g) return launch_dma_k<2, 2, 2, 2, true, true, false, 3, true>(a, s);
+    // The GEMM forms stay on 32x32x16: measured with 16x16x32 (VFML_GEMM_MF16=1) the 32400^2 volume gains 4 %, the
+    // MemFlow read-out 2 %, the 1080p field nothing - and v_mfma_f32_16x16x32_f16 is NOT symmetric in its operands to the
+    // last bit (a volume stored transposed and the reverse problem computed directly differ in the last ulp, which the
+    // 32x32x16 form never does: tests/test_gpu_kernels.py::test_wide_gemm_with_transposed_second_output), so the
+    // sliding job's "volume + transposed volume from one pass" would stop being bit-identical to from-scratch fields.
+    static const int gmf16 = getenv("VFML_GEMM_MF16") ? atoi(getenv("VFML_GEMM_MF16")) : 0;
+    if (gmf16 && a.fastk) {
+      if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true, 3, true>(a, s);
+      if (a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2, true>(a, s);
+      if (a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1, true>(a, s);
+      if (a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5, true>(a, s);
+      if (a.nm == 3) return launch_dma_k<2, 2, 2, 2, true, true, false, 3, true>(a, s);
+    }
+    if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
+    if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
+    if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
+    if (a.fastk && a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5>(a, s);
     if (a.nm == 2 && a.bhi) { vfml_set_error("vfml_conv2d_split: a weight operand without lo plane needs the uniform-step GEMM form"); return 1; }
     a.nm = 3;       // (the general-loader GEMM form exists at full precision only: never less accurate than asked)
     return a.fastk ? launch_dma_k<2, 2, 2, 2, true, true>(a, s) : launch_dma_k<2, 2, 2, 2, true, false>(a, s);

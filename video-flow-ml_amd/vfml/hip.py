@@ -206,8 +206,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
             if not fastk:
                 nm = 3
-            return (f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}, "
-                    f"{'true' if fastk else 'false'}>")   # persistent GEMM form (16x16x32 MFMAs on the uniform-step loader)
+            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}, false>"   # persistent GEMM form
         if cout <= 32:
             return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}, true>"
         if cout <= 64:
