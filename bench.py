@@ -296,9 +296,10 @@ def main():
     if prof:
         name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        split = "split" in name or "dma" in name      # the split-f16 kernels; the last template argument = MFMAs per product
+        split = "split" in name or "dma" in name or "tapx" in name      # the split-f16 kernels
         targs = [t.strip() for t in name[name.index("<") + 1:name.rindex(">")].split(",")]
-        nm_arg = int(targs[7]) if "dma" in name else (int(targs[5]) if split else 1)    # the NM template argument
+        # the NM template argument (terms of the split product): its position per kernel family
+        nm_arg = int(targs[7]) if "dma" in name else int(targs[4]) if "tapx" in name else (int(targs[5]) if split else 1)
         nm = {4: 2, 5: 1}.get(nm_arg, nm_arg)
         peak = F16_MATRIX_PEAK_TFLOPS / nm if split else F32_MATRIX_PEAK_TFLOPS
         traffic, traffic_note = hbm_traffic_from_profiles(name, args.workload)

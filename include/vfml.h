@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 19
+#define VFML_ABI_VERSION 20
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -103,7 +103,12 @@ enum { VFML_CONV_SWAP_CROSS = 1,
  *   VFML_CONV_MFMA1  both operands as one f16: a_hi w_hi - plain f16 inputs, f32 accumulate ("fp16" arithmetic).
  * The lo halves that are not used are not fetched.  Where a tile shape / loader combination is not built for the
  * reduced count the call runs with three MFMAs (never less accurate than asked). */
-       VFML_CONV_MFMA2 = 2, VFML_CONV_MFMA1 = 4, VFML_CONV_MFMA2A = 8 };
+       VFML_CONV_MFMA2 = 2, VFML_CONV_MFMA1 = 4, VFML_CONV_MFMA2A = 8,
+/* Stage the activations once per TAP (conv_gemm_dma_kernel) even where the kernel that stages them once per filter
+ * ROW and shifts the fragment reads (conv_gemm_tapx_kernel: stride-1 "same" convolutions over split-row sources with
+ * 2..5 taps per row) would take the call.  Same arithmetic in the same order - bit-identical results; for A/B
+ * measurements and the test that says so. */
+       VFML_CONV_PER_TAP = 16 };
 
 int vfml_conv2d(const vfml_conv_desc* d, void* stream);
 

@@ -839,3 +839,87 @@ def test_conv2d_one_mfma_64_channel_steps(gpu, c0, c1, cout, kh, kw, stride):
         with pytest.raises(RuntimeError, match="CBLOCK64"):
             hip.conv2d(buf, c0, LD, n, H, W, w4, None, 4, kh, kw, out, 4, stride=stride, pad_h=ph, pad_w=pw,
                        in0_off=32, in_fmt=hip.FMT_S16, mfma=1)
+
+
+@pytest.mark.parametrize("mfma", [3, 1])
+@pytest.mark.parametrize("c0,c1,cout,kh,kw,n,H,W", [
+    (64, 128, 256, 1, 5, 3, 19, 26),     # the GRU gate shape: two sources, 1x5, two column tiles of 128
+    (128, 0, 192, 3, 3, 2, 17, 23),      # 128 x 192 tiles (cout 192), 3x3: vertical taps masked at the DMA
+    (64, 0, 136, 3, 3, 1, 40, 7),        # image rows far narrower than a tile: every fragment crosses several rows
+    (64, 64, 128, 2, 4, 2, 9, 14),       # even taps (pad 1 / 2 on an even filter is not "same": refused -> per-tap path)
+    (64, 0, 256, 1, 3, 1, 3, 700),       # rows longer than a tile
+    (64, 0, 128, 3, 5, 4, 6, 5),         # four tiny images in one tile
+    (64, 0, 64, 3, 3, 2, 21, 30),        # 256 x 64 tiles (the encoders' 64-channel layers)
+    (128, 0, 96, 3, 3, 1, 33, 17),       # 256 x 96 tiles
+    (64, 0, 40, 3, 3, 1, 25, 40),        # ragged columns in a 64-wide tile
+])
+def test_tap_shared_stage_matches_the_per_tap_kernel(gpu, monkeypatch, mfma, c0, c1, cout, kh, kw, n, H, W):
+    """conv_gemm_tapx_kernel (one activation stage per filter row, fragment reads shifted per tap, zero cell for taps
+    that leave the image row) against conv_gemm_dma_kernel (VFML_CONV_PER_TAP: one stage per tap): the same products
+    in the same order, so BIT-identical outputs - and both against the float64 convolution."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(7 * c0 + kh + kw + H)
+    cin = c0 + c1
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / math.sqrt(cin * kh * kw)
+    b = torch.randn(cout, generator=g)
+    ph, pw = kh // 2, kw // 2
+    order = hip.KORDER_CBLOCK64 if mfma == 1 else hip.KORDER_CBLOCK
+    w = as_weight(pack_conv_weight(wt, cblock=64 if mfma == 1 else True), cout, "f16x3", order=order)
+    if mfma == 1:
+        ref = F.conv2d(_f16(x), _f16(wt * w.scale) / w.scale, b.double(), padding=(ph, pw)).float()
+    else:
+        ref = F.conv2d(x.double(), wt.double(), b.double(), padding=(ph, pw)).float()
+    ho, wo = ref.shape[-2:]
+    P = n * H * W
+    LD = cin + 64
+    buf = torch.zeros(P * LD, device=gpu)
+    xs = nhwc(x).view(P, cin)
+    hip.to_s16(xs[:, :c0].contiguous().reshape(-1), P, c0, c0, buf, LD, dst_off=32)
+    if c1:
+        hip.to_s16(xs[:, c0:].contiguous().reshape(-1), P, c1, c1, buf, LD, dst_off=32 + c0)
+    outs = []
+    # (problems this small would get 128 x 64 tiles: force the two shapes the shared-stage kernel is built for)
+    monkeypatch.setenv("VFML_DMA_TILE", "2,3,2,2" if cout == 192 else "2,2,4,1" if cout <= 64 else "2,3,4,1" if cout <= 96 else "3,2,2,2")
+    for per_tap in (False, True):
+        out = torch.full((n * ho * wo * cout,), float("nan"), device=gpu)
+        hip.conv2d(buf, c0, LD, n, H, W, w, b.cuda(), cout, kh, kw, out, cout, pad_h=ph, pad_w=pw, in0_off=32,
+                   in1=buf if c1 else None, c1=c1, ld1=LD if c1 else 0, in1_off=32 + c0, in_fmt=hip.FMT_S16, mfma=mfma,
+                   per_tap=per_tap)
+        outs.append(out)
+    monkeypatch.delenv("VFML_DMA_TILE")
+    got = from_nhwc(outs[0], n, ho, wo, cout)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < CONV_TOL["f16x3"], rel_err(got, ref)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_tap_shared_stage_at_the_1080p_gate_shape(gpu):
+    """The 1x5 gate convolution of a 1080p field (3 x 135 x 240 pixels, 128 + 384 channels -> 256) as the dispatcher
+    sends it by itself (192 x 128 tiles, shared stage): bit-identical to the per-tap kernel, and a band of output rows
+    against the float64 convolution."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(99)
+    n, H, W, c0, c1, cout = 3, 135, 240, 128, 384, 256
+    cin = c0 + c1
+    x = torch.randn(n, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, 1, 5, generator=g) / math.sqrt(cin * 5)
+    b = torch.randn(cout, generator=g)
+    w = as_weight(pack_conv_weight(wt, cblock=True), cout, "f16x3", order=hip.KORDER_CBLOCK)
+    P = n * H * W
+    buf = torch.zeros(P * cin, device=gpu)
+    xs = nhwc(x).view(P, cin)
+    hip.to_s16(xs[:, :c0].contiguous().reshape(-1), P, c0, c0, buf, cin)
+    hip.to_s16(xs[:, c0:].contiguous().reshape(-1), P, c1, c1, buf, cin, dst_off=c0)
+    outs = []
+    for per_tap in (False, True):
+        out = torch.full((P * cout,), float("nan"), device=gpu)
+        hip.conv2d(buf, c0, cin, n, H, W, w, b.cuda(), cout, 1, 5, out, cout, pad_w=2, in1=buf, c1=c1, ld1=cin, in1_off=c0,
+                   in_fmt=hip.FMT_S16, per_tap=per_tap)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    got = from_nhwc(outs[0], n, H, W, cout)[2:3, :, 130:135]
+    ref = F.conv2d(x[2:3, :, 130:135].double(), wt.double(), b.double(), padding=(0, 2)).float()
+    assert rel_err(got, ref) < CONV_TOL["f16x3"], rel_err(got, ref)

@@ -16,13 +16,15 @@ def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=
         x = x16
         name += " [S16]"
     wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
-    b = torch.randn(cout, device="cuda")
+    b = None if os.environ.get("MB_NOBIAS") else torch.randn(cout, device="cuda")     # MB_NOBIAS: no global load in the epilogue
+    mf = int(os.environ.get("MB_MFMA", "3"))      # 1: one MFMA per product (64-channel steps where the shape allows)
+    h64 = mf == 1 and s16 and cblock and cin % 64 == 0 and kh * kw > 1 and not gemm
     if prec != "f32" and s16 and cblock:
         from vfml.weights import pack_conv_weight
-        wc = pack_conv_weight(wt.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2), cblock=True)
+        wc = pack_conv_weight(wt.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2), cblock=64 if h64 else True)
         wobj = hip.SplitWeight(cout, wc.numel() // cout, x.device).fill(wc, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
-        wobj.order = hip.KORDER_CBLOCK
-        name += " cb"
+        wobj.order = hip.KORDER_CBLOCK64 if h64 else hip.KORDER_CBLOCK
+        name += " cb64" if h64 else " cb"
     else:
         wobj = wt if prec == "f32" else hip.SplitWeight(cout, kh * kw * cin, x.device).fill(wt, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
     out = torch.empty(n * h * w * cout * (2 if os.environ.get("MB_DUP") else 1), device="cuda")
@@ -31,7 +33,8 @@ def bench(name, n, h, w, cin, cout, kh, kw, ld=None, prec="f16x3", reps=20, s16=
             hip.conv2d(x, cin, ld, n, h, w, wobj, None, cout, kh, kw, out, cout, out_scale=1.0 / 16.0, in_fmt=fmt)
         else:
             hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, stride=stride, pad_h=kh // 2, pad_w=kw // 2,
-                       epilogue=hip.EPI_NONE if f32_out else hip.EPI_RELU, in_fmt=fmt, out_fmt=hip.FMT_F32 if f32_out else fmt)
+                       epilogue=hip.EPI_NONE if f32_out else hip.EPI_RELU, in_fmt=fmt, out_fmt=hip.FMT_F32 if f32_out else fmt,
+                       mfma=mf if (mf == 3 or (s16 and cblock)) else 3)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -69,8 +72,9 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "s16":
     bench("3x3 c256->256", 3, 135, 240, 256, 256, 3, 3, s16=True)
     bench("3x3 c256->192", 3, 135, 240, 256, 192, 3, 3, s16=True)
     bench("1x1 c656->256", 3, 135, 240, 656, 256, 1, 1, s16=True)
-    bench("gemm 32400x32400x256", 1, 1, 32400, 256, 32400, 1, 1, reps=5, s16=True, gemm=True)
-    bench("gemm 32400x8040x256", 1, 1, 32400, 256, 8040, 1, 1, reps=5, s16=True, gemm=True)
+    if os.environ.get("MB_MFMA", "3") == "3":
+        bench("gemm 32400x32400x256", 1, 1, 32400, 256, 32400, 1, 1, reps=5, s16=True, gemm=True)
+        bench("gemm 32400x8040x256", 1, 1, 32400, 256, 8040, 1, 1, reps=5, s16=True, gemm=True)
     sys.exit(0)
 
 if __name__ == "__main__":

@@ -27,212 +27,9 @@
 // vfml_split_f16 into two f16 planes [cout][Kp], zero padded.
 // Epilogue: the accumulator tile is transposed through LDS and written as float4 rows (bias,
 // activation and the GRU gate math applied on the way).
-#include <hip/hip_fp16.h>
-#include <stdlib.h>
-#include <utility>
-#include "vfml_common.h"
+#include "conv_split_common.h"
 
 namespace {
-
-// loops over compile-time indices that cannot be left to the unroller (past its size budget hipcc keeps the loop and
-// the accumulator arrays it indexes go to scratch)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int KG = BK / 8;  // 16-byte units (8 halves) per row per K step
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte load through a buffer descriptor: an offset beyond num_records returns zeros, which is how
-// padding taps, K tails and out-of-range rows/columns are filled (no branch, no select on the data).
-__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes) {
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, 0, 0));
-}
-constexpr int OOB = 0x7fffffff;   // >= any num_records we create (all < 2^31 bytes)
-
-struct SplitArgs {
-  const float* in0; const float* in1;
-  const _Float16* whi; const _Float16* wlo; const float* bias;
-  const float* aux0; const float* aux1; const float* addend;
-  float* out;
-  int c0, ld0, c1, ld1, ctot, ld_addend;
-  int H, W, ho, wo;
-  int kh, kw, stride, pad_h, pad_w;
-  int M, K, Kp, cout;
-  int d0off, d1off;             // float offsets of in0 / in1 from the common descriptor base (in0 field)
-  int bytes0, bytesw;           // descriptor extents: sources (both, from the base) and weight planes
-  int ldo, ld_aux0, ld_aux1;
-  int epilogue, split;
-  float out_scale, w_inv;
-  int mtiles, ntiles;
-  int vec_ok;  // out/aux/bias 16-byte aligned and ldo, ld_aux % 4 == 0 -> float4 epilogue
-  int out16, aux16;   // output / aux operands in the split-row format (VFML_FMT_S16)
-  // LDS-DMA kernel: both weight planes through one descriptor at wbase (byte offsets of the planes, extent)
-  const char* wbase; int whi_off, wlo_off, bytesb;
-  int korder;   // VFML_KORDER_*
-  int direct;   // LDS-DMA kernel: plain f32 output written straight from the accumulators
-  int pointwise;  // 1x1 / stride 1 / no padding
-  // uniform-step loader of the LDS-DMA kernel (channel-block order, whole 32-channel blocks per source,
-  // one row stride): per K step the tap / channel offset is one scalar
-  int fastk, abias, src1_delta;
-  int tilebase;   // 1x1 over one source: the source descriptor starts at the tile's first row (sources > 2 GiB)
-  float* out_t; int ld_out_t;   // GEMM form: transposed second output (or null)
-  int cswap;                    // VFML_CONV_SWAP_CROSS
-  int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
-  double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
-  int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
-};
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-union U8 {
-  h16x8 v;
-  h16x2 p[4];
-};
-
-// x (4 floats) -> hi/lo halves at element offset `at` (0 or 4) of the 8-wide units
-__device__ __forceinline__ void split4(const f32x4 x, U8& hi, U8& lo, int at) {
-#pragma unroll
-  for (int e = 0; e < 2; ++e) vfml_split2(x[2 * e], x[2 * e + 1], hi.p[at / 2 + e], lo.p[at / 2 + e]);
-}
-
-__device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float x0, float x1) {
-  switch (epilogue) {
-    case VFML_EPI_RELU: return fmaxf(v, 0.f);
-    case VFML_EPI_TANH: return tanhf(v);
-    case VFML_EPI_SIGMOID: return sigmoidf_(v);
-    case VFML_EPI_TANH_RELU: return lowhalf ? tanhf(v) : fmaxf(v, 0.f);
-    case VFML_EPI_GRU_ZR: v = sigmoidf_(v); return lowhalf ? v : v * x0;
-    case VFML_EPI_GRU_Q: return (1.f - x0) * x1 + x0 * tanhf(v);
-    case VFML_EPI_ADD_AUX: return x0 + v;
-    default: return v;
-  }
-}
-
-// accumulator tiles of one wave -> the workgroup's fp32 tile in LDS (row stride LDC floats)
-template <int TM, int TN, int LDC>
-__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[TM][TN], float* sC, int row0, int col0, int r, int half) {
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int col = col0 + j * 32 + r;
-        sC[row * LDC + col] = acc[i][j][e];
-      }
-}
-
-// the LDS tile -> global rows: bias, addend, activation / GRU gate math, f32 or split-row stores
-template <int BN, int NT>
-__device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* sC, int m0, int n0, int t,
-                                              int nrows = BM, int rstride = 32, int roff = 0) {
-  // LDS row `row` is output pixel m0 + (row / 32) * rstride + roff + row % 32 (identity by default; the
-  // LDS-DMA kernel passes the tile through in slabs of one 32-row block per wave row)
-  constexpr int LDC = BN + 4;
-  // 8 channels (one split-row unit) per thread, as two quads
-  constexpr int C8 = BN / 8;
-  constexpr int RPP = NT / C8;       // rows per pass
-  const int c8 = t % C8;
-  const int gcol = n0 + c8 * 8;
-  if (gcol >= a.cout) return;
-  const int epi = a.epilogue;
-  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if (a.bias) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (gcol + e < a.cout) bias4[e >> 2][e & 3] = a.bias[gcol + e];
-  }
-  // reads 4 channels at (row, col) of an aux operand in either format
-  auto aux4 = [&](const float* base, int ld, int64_t row, int col) -> f32x4 {
-    f32x4 x;
-    if (a.aux16) {
-      const char* u = reinterpret_cast<const char*>(base + row * ld + (col & ~7)) + (col & 4) * 2;
-      const h16x2 h0 = *reinterpret_cast<const h16x2*>(u), h1 = *reinterpret_cast<const h16x2*>(u + 4);
-      const h16x2 l0 = *reinterpret_cast<const h16x2*>(u + 16), l1 = *reinterpret_cast<const h16x2*>(u + 20);
-      x[0] = (float)h0[0] + (float)l0[0];
-      x[1] = (float)h0[1] + (float)l0[1];
-      x[2] = (float)h1[0] + (float)l1[0];
-      x[3] = (float)h1[1] + (float)l1[1];
-    } else if (a.vec_ok) {
-      x = *reinterpret_cast<const f32x4*>(base + row * ld + col);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = base[row * ld + col + e];
-    }
-    return x;
-  };
-  for (int row = t / C8; row < nrows; row += RPP) {
-    const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
-    if (grow >= a.M) continue;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int col = gcol + 4 * q;
-      if (col >= a.cout) break;
-      const bool lowhalf = col < a.split;   // split is a multiple of 4: a quad never straddles it
-      const int nvalid = a.cout - col >= 4 ? 4 : a.cout - col;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4 * q]);
-      f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
-      if (a.addend) {
-        if (nvalid == 4 && a.vec_ok) {
-          add4 = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + col);
-        } else {
-          for (int e = 0; e < nvalid; ++e) add4[e] = a.addend[(int64_t)grow * a.ld_addend + col + e];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + add4[e] + bias4[q][e]) * a.out_scale;
-      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-      if (nvalid == 4) {
-        if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0 = aux4(a.aux0, a.ld_aux0, grow, col - a.split);
-        if (epi == VFML_EPI_GRU_Q) {
-          x0 = aux4(a.aux0, a.ld_aux0, grow, col);
-          x1 = aux4(a.aux1, a.ld_aux1, grow, col);
-        }
-        if (epi == VFML_EPI_ADD_AUX) x0 = aux4(a.aux0, a.ld_aux0, grow, col);
-      } else {
-        for (int e = 0; e < nvalid; ++e) {   // ragged tail: f32 operands only (host check)
-          if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e - a.split];
-          if (epi == VFML_EPI_GRU_Q) {
-            x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
-            x1[e] = a.aux1[(int64_t)grow * a.ld_aux1 + col + e];
-          }
-          if (epi == VFML_EPI_ADD_AUX) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = epi1(v[e], epi, lowhalf, x0[e], x1[e]);
-      if (a.out16) {
-        // hi quad at unit + 8q bytes, lo quad at unit + 16 + 8q (cout % 4 == 0, host check)
-        U8 hi, lo;
-        split4(v, hi, lo, 0);
-        char* u = reinterpret_cast<char*>(a.out + (int64_t)grow * a.ldo + gcol) + 8 * q;
-        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
-        *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
-      } else {
-        float* o = a.out + (int64_t)grow * a.ldo + col;
-        if (nvalid == 4 && a.vec_ok) {
-          *reinterpret_cast<f32x4*>(o) = v;
-        } else {
-          for (int e = 0; e < nvalid; ++e) o[e] = v[e];
-        }
-      }
-    }
-  }
-}
 
 // BIGC: every source row has >= BK channels, so a K step never spans more than two taps and the
 // (channel, tap) state advances without divisions.  !BIGC (4-channel stem / flow convs) recomputes
@@ -547,14 +344,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 // (both planes lie in one descriptor window).
 // Two LDS stages; the DMAs of step k+1 are issued right after the barrier that opens step k and are
 // waited for (vmcnt(0)) before the next one, so they have a whole step of MFMAs to land.
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, char* lds) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // address = base + voffset + soffset; only voffset is range-checked (an out-of-range lane writes zeros)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff_bytes, soff_bytes, 0, 0);
-#endif
-}
 
 // Waves WM x WN, each 32*TM x 32*TN outputs; 4 waves run two workgroups per CU, 8 waves one.
 // The grid is persistent: a workgroup walks tiles start + lw, start + lw + nl, ... of its XCD's
@@ -575,7 +364,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 // clock on the 16x16 shape under an MFMA-dense load (MI355X_MICROARCH.md, DVFS give-back item 7).  The lane -> (row,
 // piece) map of a fragment read differs, so the bank swizzle of the LDS image does too (swz16 below); the
 // accumulators are 16 x 16 tiles (4 registers each).  Not built for the persistent GEMM form.
-__device__ __forceinline__ constexpr int swz16(int x) { return x ^ ((((x >> 1) ^ (x >> 2)) & 1) << 1); }
 
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
@@ -1413,19 +1201,11 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
 template <int TM, int TN, int WM, int WN>
 int launch_dma(SplitArgs& a, hipStream_t s) {
   if (a.direct) {   // (128 x 128: the one persistent tile shape that does not spill)
-    // The GEMM forms stay on 32x32x16: measured with 16x16x32 (VFML_GEMM_MF16=1) the 32400^2 volume gains 4 %, the
+    // The GEMM forms stay on 32x32x16: measured with 16x16x32 (an experiment since removed) the 32400^2 volume gains 4 %, the
     // MemFlow read-out 2 %, the 1080p field nothing - and v_mfma_f32_16x16x32_f16 is NOT symmetric in its operands to the
     // last bit (a volume stored transposed and the reverse problem computed directly differ in the last ulp, which the
     // 32x32x16 form never does: tests/test_gpu_kernels.py::test_wide_gemm_with_transposed_second_output), so the
     // sliding job's "volume + transposed volume from one pass" would stop being bit-identical to from-scratch fields.
-    static const int gmf16 = getenv("VFML_GEMM_MF16") ? atoi(getenv("VFML_GEMM_MF16")) : 0;
-    if (gmf16 && a.fastk) {
-      if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true, 3, true>(a, s);
-      if (a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2, true>(a, s);
-      if (a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1, true>(a, s);
-      if (a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5, true>(a, s);
-      if (a.nm == 3) return launch_dma_k<2, 2, 2, 2, true, true, false, 3, true>(a, s);
-    }
     if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
     if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
     if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
@@ -1816,7 +1596,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
   {
     const int pbits = d->flags & (VFML_CONV_MFMA2 | VFML_CONV_MFMA1 | VFML_CONV_MFMA2A);
-    VFML_REQUIRE((d->flags & ~(VFML_CONV_SWAP_CROSS | VFML_CONV_MFMA2 | VFML_CONV_MFMA1 | VFML_CONV_MFMA2A)) == 0,
+    VFML_REQUIRE((d->flags & ~(VFML_CONV_SWAP_CROSS | VFML_CONV_MFMA2 | VFML_CONV_MFMA1 | VFML_CONV_MFMA2A | VFML_CONV_PER_TAP)) == 0,
                  "vfml_conv2d_split: unknown flag bits");
     VFML_REQUIRE((pbits & (pbits - 1)) == 0 && !((d->flags & VFML_CONV_SWAP_CROSS) && pbits),
                  "vfml_conv2d_split: VFML_CONV_MFMA2 / _MFMA2A / _MFMA1 / _SWAP_CROSS exclude one another");
@@ -2004,7 +1784,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                      "epilogue, pixels %% 4 == 0, ld_out_t %% 4 == 0 and >= pixels, 16-byte alignment");
         a.out_t = d->out_t; a.ld_out_t = d->ld_out_t;
       }
-      static const char* tile_env = getenv("VFML_DMA_TILE");   // experiments: "TM,TN,WM,WN"
+      const char* tile_env = getenv("VFML_DMA_TILE");   // experiments / tests: "TM,TN,WM,WN" (read per call)
       int cfg = d->cout > 32 ? 2122 : 1141;
       if (d->cout > 64) {
         // 192 x 128, 128 x 192, 128 x 128 or 128 x 64 tiles (two workgroups per CU each).  Cost model:
@@ -2024,10 +1804,21 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         if (c2222 < best) { best = c2222; cfg = 2222; }
         if (c2122 < best) { best = c2122; cfg = 2122; }
       }
-      if (tile_env && d->cout > 64) {
+      bool forced = false;
+      if (tile_env && d->cout > 32) {
         int tm = 2, tn = 2, wm = 2, wn = 2;
         sscanf(tile_env, "%d,%d,%d,%d", &tm, &tn, &wm, &wn);
-        cfg = tm * 1000 + tn * 100 + wm * 10 + wn;
+        const int want = tm * 1000 + tn * 100 + wm * 10 + wn;
+        // (2241 / 2341 exist in the shared-stage kernel only; narrower outputs keep their per-tap shapes otherwise)
+        if (d->cout > 64 || want == 2241 || want == 2341) { cfg = want; forced = true; }
+      }
+      // stride-1 "same" convolutions with a filter row of 2..5 taps: one activation stage per (channel block, tap row),
+      // shared by the row's taps (conv_gemm_tapx.hip; VFML_TAPX=0: the per-tap stages of conv_gemm_dma_kernel, for A/B)
+      static const int tapx = getenv("VFML_TAPX") ? atoi(getenv("VFML_TAPX")) : 1;
+      if (tapx && !(d->flags & VFML_CONV_PER_TAP)) {
+        // (VFML_TAPX=2: also the three-MFMA calls on the 192 x 128 / 128 x 192 tiles, where the two kernels run level)
+        const int tcfg = vfml_detail::tapx_cfg(a, cfg, forced);
+        if (tcfg && (tapx >= 2 || forced || a.nm == 5 || tcfg == 2241 || tcfg == 2341)) return vfml_detail::launch_tapx(a, tcfg, s);
       }
       switch (cfg) {
         case 3222: return launch_dma<3, 2, 2, 2>(a, s);   // 192 x 128, 2 workgroups per CU
@@ -2037,6 +1828,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         case 4224: return launch_dma<4, 2, 2, 4>(a, s);   // 256 x 256, 8 waves
         case 2122: return launch_dma<2, 1, 2, 2>(a, s);   // 128 x 64
         case 1141: return launch_dma<1, 1, 4, 1>(a, s);   // 128 x 32
+        case 2241: case 2341: return launch_dma<2, 1, 2, 2>(a, s);   // (forced shared-stage shapes on a call that kernel does not take)
         default: return launch_dma<2, 2, 2, 2>(a, s);
       }
     }

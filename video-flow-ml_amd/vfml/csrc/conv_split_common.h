@@ -1,0 +1,244 @@
+// Shared by the split-f16 convolution translation units (conv_gemm_split.hip, conv_gemm_tapx.hip): argument block,
+// compile-time loops, the LDS-DMA primitive, the bank swizzle of the 16x16x32 LDS image and the epilogue that turns a
+// workgroup's fp32 tile in LDS into global rows.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <stdlib.h>
+#include <utility>
+#include "vfml_common.h"
+
+
+namespace vfml_detail {
+struct SplitArgs {
+  const float* in0; const float* in1;
+  const _Float16* whi; const _Float16* wlo; const float* bias;
+  const float* aux0; const float* aux1; const float* addend;
+  float* out;
+  int c0, ld0, c1, ld1, ctot, ld_addend;
+  int H, W, ho, wo;
+  int kh, kw, stride, pad_h, pad_w;
+  int M, K, Kp, cout;
+  int d0off, d1off;             // float offsets of in0 / in1 from the common descriptor base (in0 field)
+  int bytes0, bytesw;           // descriptor extents: sources (both, from the base) and weight planes
+  int ldo, ld_aux0, ld_aux1;
+  int epilogue, split;
+  float out_scale, w_inv;
+  int mtiles, ntiles;
+  int vec_ok;  // out/aux/bias 16-byte aligned and ldo, ld_aux % 4 == 0 -> float4 epilogue
+  int out16, aux16;   // output / aux operands in the split-row format (VFML_FMT_S16)
+  // LDS-DMA kernel: both weight planes through one descriptor at wbase (byte offsets of the planes, extent)
+  const char* wbase; int whi_off, wlo_off, bytesb;
+  int korder;   // VFML_KORDER_*
+  int direct;   // LDS-DMA kernel: plain f32 output written straight from the accumulators
+  int pointwise;  // 1x1 / stride 1 / no padding
+  // uniform-step loader of the LDS-DMA kernel (channel-block order, whole 32-channel blocks per source,
+  // one row stride): per K step the tap / channel offset is one scalar
+  int fastk, abias, src1_delta;
+  int tilebase;   // 1x1 over one source: the source descriptor starts at the tile's first row (sources > 2 GiB)
+  float* out_t; int ld_out_t;   // GEMM form: transposed second output (or null)
+  int cswap;                    // VFML_CONV_SWAP_CROSS
+  int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
+  double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
+  int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
+};
+// conv_gemm_tapx.hip: the kernel that shares one activation stage between the taps of a filter row
+#define VFML_TAPX_KWMAX 5      // widest filter row it is built for
+int tapx_cfg(const SplitArgs& a, int cfg, bool forced);       // cfg = tile shape as TM TN WM WN digits; 0: not its call
+int launch_tapx(SplitArgs& a, int cfg, hipStream_t s);
+}  // namespace vfml_detail
+using vfml_detail::SplitArgs;
+
+namespace {
+
+// loops over compile-time indices that cannot be left to the unroller (past its size budget hipcc keeps the loop and
+// the accumulator arrays it indexes go to scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int KG = BK / 8;  // 16-byte units (8 halves) per row per K step
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: an offset beyond num_records returns zeros, which is how
+// padding taps, K tails and out-of-range rows/columns are filled (no branch, no select on the data).
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, 0, 0));
+}
+constexpr int OOB = 0x7fffffff;   // >= any num_records we create (all < 2^31 bytes)
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+union U8 {
+  h16x8 v;
+  h16x2 p[4];
+};
+
+// x (4 floats) -> hi/lo halves at element offset `at` (0 or 4) of the 8-wide units
+__device__ __forceinline__ void split4(const f32x4 x, U8& hi, U8& lo, int at) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) vfml_split2(x[2 * e], x[2 * e + 1], hi.p[at / 2 + e], lo.p[at / 2 + e]);
+}
+
+__device__ __forceinline__ float epi1(float v, int epilogue, bool lowhalf, float x0, float x1) {
+  switch (epilogue) {
+    case VFML_EPI_RELU: return fmaxf(v, 0.f);
+    case VFML_EPI_TANH: return tanhf(v);
+    case VFML_EPI_SIGMOID: return sigmoidf_(v);
+    case VFML_EPI_TANH_RELU: return lowhalf ? tanhf(v) : fmaxf(v, 0.f);
+    case VFML_EPI_GRU_ZR: v = sigmoidf_(v); return lowhalf ? v : v * x0;
+    case VFML_EPI_GRU_Q: return (1.f - x0) * x1 + x0 * tanhf(v);
+    case VFML_EPI_ADD_AUX: return x0 + v;
+    default: return v;
+  }
+}
+
+// accumulator tiles of one wave -> the workgroup's fp32 tile in LDS (row stride LDC floats)
+template <int TM, int TN, int LDC>
+__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[TM][TN], float* sC, int row0, int col0, int r, int half) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int col = col0 + j * 32 + r;
+        sC[row * LDC + col] = acc[i][j][e];
+      }
+}
+
+// the LDS tile -> global rows: bias, addend, activation / GRU gate math, f32 or split-row stores
+template <int BN, int NT>
+__device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* sC, int m0, int n0, int t,
+                                              int nrows = BM, int rstride = 32, int roff = 0) {
+  // LDS row `row` is output pixel m0 + (row / 32) * rstride + roff + row % 32 (identity by default; the
+  // LDS-DMA kernel passes the tile through in slabs of one 32-row block per wave row)
+  constexpr int LDC = BN + 4;
+  // 8 channels (one split-row unit) per thread, as two quads
+  constexpr int C8 = BN / 8;
+  constexpr int RPP = NT / C8;       // rows per pass
+  const int c8 = t % C8;
+  const int gcol = n0 + c8 * 8;
+  if (gcol >= a.cout) return;
+  const int epi = a.epilogue;
+  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (a.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (gcol + e < a.cout) bias4[e >> 2][e & 3] = a.bias[gcol + e];
+  }
+  // reads 4 channels at (row, col) of an aux operand in either format
+  auto aux4 = [&](const float* base, int ld, int64_t row, int col) -> f32x4 {
+    f32x4 x;
+    if (a.aux16) {
+      const char* u = reinterpret_cast<const char*>(base + row * ld + (col & ~7)) + (col & 4) * 2;
+      const h16x2 h0 = *reinterpret_cast<const h16x2*>(u), h1 = *reinterpret_cast<const h16x2*>(u + 4);
+      const h16x2 l0 = *reinterpret_cast<const h16x2*>(u + 16), l1 = *reinterpret_cast<const h16x2*>(u + 20);
+      x[0] = (float)h0[0] + (float)l0[0];
+      x[1] = (float)h0[1] + (float)l0[1];
+      x[2] = (float)h1[0] + (float)l1[0];
+      x[3] = (float)h1[1] + (float)l1[1];
+    } else if (a.vec_ok) {
+      x = *reinterpret_cast<const f32x4*>(base + row * ld + col);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = base[row * ld + col + e];
+    }
+    return x;
+  };
+  for (int row = t / C8; row < nrows; row += RPP) {
+    const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
+    if (grow >= a.M) continue;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = gcol + 4 * q;
+      if (col >= a.cout) break;
+      const bool lowhalf = col < a.split;   // split is a multiple of 4: a quad never straddles it
+      const int nvalid = a.cout - col >= 4 ? 4 : a.cout - col;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4 * q]);
+      f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
+      if (a.addend) {
+        if (nvalid == 4 && a.vec_ok) {
+          add4 = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + col);
+        } else {
+          for (int e = 0; e < nvalid; ++e) add4[e] = a.addend[(int64_t)grow * a.ld_addend + col + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] * a.w_inv + add4[e] + bias4[q][e]) * a.out_scale;
+      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+      if (nvalid == 4) {
+        if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0 = aux4(a.aux0, a.ld_aux0, grow, col - a.split);
+        if (epi == VFML_EPI_GRU_Q) {
+          x0 = aux4(a.aux0, a.ld_aux0, grow, col);
+          x1 = aux4(a.aux1, a.ld_aux1, grow, col);
+        }
+        if (epi == VFML_EPI_ADD_AUX) x0 = aux4(a.aux0, a.ld_aux0, grow, col);
+      } else {
+        for (int e = 0; e < nvalid; ++e) {   // ragged tail: f32 operands only (host check)
+          if (epi == VFML_EPI_GRU_ZR && !lowhalf) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e - a.split];
+          if (epi == VFML_EPI_GRU_Q) {
+            x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
+            x1[e] = a.aux1[(int64_t)grow * a.ld_aux1 + col + e];
+          }
+          if (epi == VFML_EPI_ADD_AUX) x0[e] = a.aux0[(int64_t)grow * a.ld_aux0 + col + e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = epi1(v[e], epi, lowhalf, x0[e], x1[e]);
+      if (a.out16) {
+        // hi quad at unit + 8q bytes, lo quad at unit + 16 + 8q (cout % 4 == 0, host check)
+        U8 hi, lo;
+        split4(v, hi, lo, 0);
+        char* u = reinterpret_cast<char*>(a.out + (int64_t)grow * a.ldo + gcol) + 8 * q;
+#ifdef VFML_EXPERIMENT_NOEPISTORE     // timing only: the values are consumed, nothing is written
+        asm volatile("" ::"v"(hi.v), "v"(lo.v), "v"(u));
+#else
+        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+        *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+#endif
+      } else {
+        float* o = a.out + (int64_t)grow * a.ldo + col;
+        if (nvalid == 4 && a.vec_ok) {
+          *reinterpret_cast<f32x4*>(o) = v;
+        } else {
+          for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+        }
+      }
+    }
+  }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes, char* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // address = base + voffset + soffset; only voffset is range-checked (an out-of-range lane writes zeros)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff_bytes, soff_bytes, 0, 0);
+#endif
+}
+
+// workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every outstanding global store
+// (vmcnt(0)), which serialises an epilogue's slabs on the store round trip
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// bank swizzle of the LDS image read by 16x16x32 fragments (conv_gemm_dma_kernel, MF16)
+__device__ __forceinline__ constexpr int swz16(int x) { return x ^ ((((x >> 1) ^ (x >> 2)) & 1) << 1); }
+
+}  // namespace

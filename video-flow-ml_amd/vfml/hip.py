@@ -14,13 +14,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFML_LIB") or os.path.join(_HERE, "libvfml_hip.so")   # VFML_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
 
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
 KORDER_TAP, KORDER_CBLOCK, KORDER_CBLOCK64 = 0, 1, 2   # K-axis order of split weight planes (include/vfml.h)
-CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1, CONV_MFMA2A = 1, 2, 4, 8   # vfml_conv_desc.flags
+CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1, CONV_MFMA2A, CONV_PER_TAP = 1, 2, 4, 8, 16   # vfml_conv_desc.flags
 
 
 class ConvDesc(ctypes.Structure):
@@ -46,11 +46,33 @@ class ConvDesc(ctypes.Structure):
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into libvfml_hip.so (in-tree). Cross-compiles without a GPU."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "vfml_common.h"),
-                   os.path.join(_HERE, "..", "..", "include", "vfml.h")]
+    hdrs = [os.path.join(CSRC, "vfml_common.h"), os.path.join(CSRC, "conv_split_common.h"),
+            os.path.join(_HERE, "..", "..", "include", "vfml.h")]
+    deps = srcs + hdrs
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
+    # one object per source, compiled side by side (objects kept under csrc/_obj: a changed source recompiles alone)
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [
+        os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
@@ -107,7 +129,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 19:
+    if L.vfml_abi_version() != 20:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -193,7 +215,7 @@ def profile_end():
 
 
 def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False,
-                 cswap=False, nm=3):
+                 cswap=False, nm=3, same=None, per_tap=False, stats=False):
     """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
     the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
     split kernel for cout > 64 is not modelled)."""
@@ -209,6 +231,17 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
             return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}, false>"   # persistent GEMM form
         if cout <= 32:
             return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}, true>"
+        # the shared-stage kernel (csrc/conv_gemm_tapx.hip: vfml_detail::tapx_cfg and the dispatcher's condition):
+        # `same` = (kh, kw) of a stride-1 "same" convolution, else None
+        tapx_mode = int(os.environ.get("VFML_TAPX", "1"))
+        tapx = (tapx_mode and not per_tap and fastk and same is not None and 2 <= same[1] <= 5 and same[0] <= 4
+                and nm in (3, 5))
+        tiles256 = -(-m // 256)
+        fills = tiles256 * 100 >= -(-tiles256 // 512) * 512 * 85      # 256-row tiles fill their last round to 85 %
+        if tapx and cout <= 64 and fills:
+            return f"conv_gemm_tapx_kernel<2, 2, 4, 1, {nm}>"
+        if tapx and 64 < cout <= 96 and fills:
+            return f"conv_gemm_tapx_kernel<2, 3, 4, 1, {nm}>"
         if cout <= 64:
             return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, {nm}, true>"
         def cost(tbm, tbn, mf, eff):
@@ -221,6 +254,8 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         for c, name in cands[1:]:
             if c < best:
                 best, t = c, name
+        if tapx and t in ("3, 2, 2, 2", "2, 3, 2, 2") and (nm == 5 or tapx_mode >= 2):
+            return f"conv_gemm_tapx_kernel<{t}, {nm}>"
         return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, {nm}, true>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}, {nm}>"
@@ -267,10 +302,11 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
-           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3):
+           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3, per_tap=False):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers).  mfma: terms of the split-f16 product (3; 2 or "2w" = weights as plain
-    f16; "2a" = activations as plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA2A / _MFMA1)."""
+    f16; "2a" = activations as plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA2A / _MFMA1).  per_tap:
+    VFML_CONV_PER_TAP (the per-tap staging kernel where the shared-stage one would run; same bits)."""
     d = ConvDesc()
     d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
     d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
@@ -289,7 +325,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         mfma = 2
     if mfma not in (1, 2, 3, "2a") or (swap_cross and mfma != 3):
         raise ValueError(f"mfma={mfma!r}: 1, 2 ('2w'), '2a' or 3 (3 with swap_cross)")
-    d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, "2a": CONV_MFMA2A, 1: CONV_MFMA1}[mfma]
+    d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, "2a": CONV_MFMA2A, 1: CONV_MFMA1}[mfma] | (CONV_PER_TAP if per_tap else 0)
     d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
@@ -325,8 +361,9 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         nm_eff = 5                                           # 64-channel steps of hi halves
     elif is_split and weight.lo is None:
         nm_eff = {3: 2, 2: 2, 4: 1, 1: 1}[nm_eff]            # a single weight plane has no lo half to use
+    same = (kh, kw) if (stride == 1 and ho == h and wo == w and not pointwise) else None
     _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
-                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross, nm_eff),
+                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross, nm_eff, same, per_tap),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)
