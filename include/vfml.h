@@ -231,6 +231,13 @@ int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, cons
                               float* out, int ld_out, int out_fmt, void* stream);
 int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream);
 
+/* A 3x3 "same" convolution with FOUR output channels as a 1x1 convolution to 36 (tap-major: column (ky*3+kx)*4 + o holds
+ * sum_c w[o][c][ky][kx] x[.][c]) followed by this pass: out[p][o] = bias[o] + sum over the nine taps inside the image of
+ * t[p + (ky-1) w + (kx-1)][(ky*3+kx)*4 + o], taps in ky-major order.  The update block's flow head (256 -> 4) costs nine
+ * times fewer MFMA steps this way than as a 3x3 convolution padded to a 32-column tile.  t: [n*h*w][ld_t] f32 (ld_t >= 36,
+ * multiple of 4, 16-byte aligned rows), bias: 4 floats or NULL, out: [n*h*w][4] f32. */
+int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, void* stream);
+
 /* coords1 += delta (4 floats per pixel: fwd x,y, bwd x,y); flow = coords1 - grid is written to
  * flow_a[p*ld_a..+4] and flow_b[p*ld_b..+4] (either may be NULL).  h,w give the pixel grid,
  * n maps. delta may be NULL (just (re)emit flow).  */

@@ -923,3 +923,25 @@ def test_tap_shared_stage_at_the_1080p_gate_shape(gpu):
     got = from_nhwc(outs[0], n, H, W, cout)[2:3, :, 130:135]
     ref = F.conv2d(x[2:3, :, 130:135].double(), wt.double(), b.double(), padding=(0, 2)).float()
     assert rel_err(got, ref) < CONV_TOL["f16x3"], rel_err(got, ref)
+
+
+@pytest.mark.parametrize("n,H,W", [(2, 9, 14), (1, 1, 5), (3, 135, 240)])
+def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
+    """vfml_tapsum3x3 over the tap-major 1x1 products == the 3x3 'same' convolution to four channels (zero padding)."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(n, 24, H, W, generator=g, dtype=torch.float64)
+    wt = torch.randn(4, 24, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(4, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, wt, b, padding=1).float()
+    w36 = wt.permute(2, 3, 0, 1).reshape(36, 24)                      # row (ky*3+kx)*4 + o
+    t = torch.einsum("nchw,kc->nhwk", x, w36).float()                 # the 1x1 convolution's output
+    ld = 40
+    tp = torch.zeros(n * H * W, ld)
+    tp[:, :36] = t.reshape(-1, 36)
+    out = torch.full((n * H * W * 4,), float("nan"), device=gpu)
+    hip.tapsum3x3(tp.cuda().reshape(-1), ld, b.float().cuda(), n, H, W, out)
+    got = out.view(n, H, W, 4).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) < 2e-6
+    with pytest.raises(RuntimeError, match="ld_t"):
+        hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)

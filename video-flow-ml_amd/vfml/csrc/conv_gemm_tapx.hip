@@ -42,10 +42,7 @@ extern "C" int vfml_debug_tapx_stamps(unsigned long long* out) {
 
 namespace {
 
-// BREG: the weight fragments do not pass through LDS at all: each wave loads the 16 couts x 64 bytes of its fragments from the
-// (L2-resident) weight planes straight into registers, one step ahead (two register sets).  No weight stage, no barrier X, no
-// exposed fragment-read latency at the head of a step; a barrier only where the activation stage changes (once per filter row).
-template <int TM, int TN, int WM, int WN, int NM, bool BREG = false>
+template <int TM, int TN, int WM, int WN, int NM>
 __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs a) {
   constexpr bool H64 = NM == 5;                       // one MFMA per product over 64-channel steps of hi halves
   constexpr bool BHI = NM == 2 || NM == 1 || H64;     // weight lo slots unused
@@ -58,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
   constexpr int NPI = (NPA + 3) / 4;                         // ... per wave (piece p = 4 i + wave)
   constexpr int BP = TBN / 32;                               // weight pieces per wave and step
   constexpr int ASZ = NPA * 1024, BSZ = TBN * 128;
-  constexpr int BOFF = 2 * ASZ, ZOFF = BOFF + (BREG ? 0 : BSZ);   // [A0][A1][B][128 B of zeros]  (BREG: no B)
+  constexpr int BOFF = 2 * ASZ, ZOFF = BOFF + BSZ;           // [A0][A1][B][128 B of zeros]
   constexpr int LDC = TBN + 4;
   static_assert(ZOFF % 128 == 0, "the zero cell must keep the fragment address bits 4..6 free");
   constexpr int ASLOTS = (NPI + 1) / 2;                      // issue slots per step for pieces of the next activation stage (kw >= 2)
@@ -139,22 +136,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
                                                           : 0x40000000;
   }
 
-  // BREG: byte offset in the hi plane of the lane's 16 bytes of weight fragment j (16 couts x 32 channels; lane -> cout
-  // lane & 15, 8-channel unit lane >> 4) at step 0
-  int bvoff[2 * TN];
-#pragma unroll
-  for (int j = 0; j < 2 * TN; ++j) {
-    const int col = n0 + (wave % WN) * (32 * TN) + j * 16 + (lane & 15);
-    bvoff[j] = col < a.cout ? a.whi_off + col * a.Kp * 2 + (lane >> 4) * 16 : 0x40000000;
-  }
-  const int lo_delta = a.wlo_off - a.whi_off;
-  auto load_b = [&](int stn, h16x8 (&d0)[2 * TN], h16x8 (&d1)[2 * TN], int j) {
-    const int soff = stn * (H64 ? 128 : 64);
-    d0[j] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff[j], soff, 0));
-    if constexpr (H64) d1[j] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff[j], soff + 64, 0));
-    else if constexpr (!BHI) d1[j] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, bvoff[j] + lo_delta, soff, 0));
-  };
-
   // activation piece i of the stage (channel block cbn, tap row kyn) -> buffer nbuf
   auto issue_a = [&](int i, int nbuf, int cbn, int kyn) {
     const int cl = cbn < a.c0 ? cbn : cbn - a.c0;
@@ -195,14 +176,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
 #pragma unroll
   for (int i = 0; i < NPI; ++i)
     if (4 * i + wave < NPA) issue_a(i, 0, 0, 0);
-  h16x8 b0[2 * TN], b1[2 * TN];          // this step's weight fragments
-  if constexpr (BREG) {
 #pragma unroll
-    for (int j = 0; j < 2 * TN; ++j) load_b(0, b0, b1, j);
-  } else {
-#pragma unroll
-    for (int j = 0; j < BP; ++j) issue_b(j, 0);
-  }
+  for (int j = 0; j < BP; ++j) issue_b(j, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -228,15 +203,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
 #endif
       STAMP(c0);
       // this step's weight fragments into registers, then the weight stage is free for the next step's pieces
-      h16x8 nb0[2 * TN], nb1[2 * TN];      // BREG: the next step's, loaded behind the first MFMA groups
-      if constexpr (!BREG) {
+      // (the fragments straight from the L2-resident weight planes into registers one step ahead - no weight stage, no
+      // barrier X - measured 20-25 % slower: a fragment is 16 rows x 64 bytes, sixteen cache lines per load instruction)
+      h16x8 b0[2 * TN], b1[2 * TN];
 #pragma unroll
-        for (int j = 0; j < 2 * TN; ++j) {
-          b0[j] = *reinterpret_cast<const h16x8*>(smem_raw + boff4 + j * 2048);
-          if constexpr (H64 || !BHI) b1[j] = *reinterpret_cast<const h16x8*>(smem_raw + (boff4 ^ X1) + j * 2048);
-        }
+      for (int j = 0; j < 2 * TN; ++j) {
+        b0[j] = *reinterpret_cast<const h16x8*>(smem_raw + boff4 + j * 2048);
+        if constexpr (H64 || !BHI) b1[j] = *reinterpret_cast<const h16x8*>(smem_raw + (boff4 ^ X1) + j * 2048);
       }
-      const int stn = st + 1 < nsteps ? st + 1 : st;     // (the last step reloads its own: no conditional load)
       // fragment address of tile row 0 under this tap: staged row r4 + kx (the swizzle follows the shifted row)
       const int R0 = r4 + kx;
       const int swa = (R0 >> 1) & 7;
@@ -248,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
         a0 = *reinterpret_cast<const h16x8*>(smem_raw + ad);
         if constexpr (H64 || !AHI) a1 = *reinterpret_cast<const h16x8*>(smem_raw + (ad ^ X1));
       }
-      if constexpr (!BREG) __syncthreads();                                                // (X)
+      __syncthreads();                                                                     // (X)
       STAMP(c1);
       __builtin_amdgcn_sched_barrier(0);
       static_for<2 * TM>([&](auto ic) {
@@ -271,14 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
           }
           // behind the first groups: the next step's weight pieces, then this step's share of the next activation stage
           constexpr int g = i * (2 * TN) + j;
-          if constexpr (BREG) {
-            if constexpr (g < 2 * TN) {
-              load_b(stn, nb0, nb1, g);
-            } else if constexpr (g < 2 * TN + ASLOTS) {
-              const int ia = kx + (g - 2 * TN) * a.kw;
-              if (next_stage && ia < NPI && 4 * ia + wave < NPA) issue_a(ia, nbuf, cbn, kyn);
-            }
-          } else if constexpr (g < BP) {
+          if constexpr (g < BP) {
             if (next_step) issue_b(g, st + 1);
           } else if constexpr (g < BP + ASLOTS) {
             const int ia = kx + (g - BP) * a.kw;
@@ -292,22 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
         }
       });
       STAMP(c2);
-      if constexpr (BREG) {
-#pragma unroll
-        for (int j = 0; j < 2 * TN; ++j) {
-          b0[j] = nb0[j];
-          if constexpr (H64 || !BHI) b1[j] = nb1[j];
-        }
-        if (kx + 1 == a.kw) {               // the activation stage changes: its pieces landed, its readers are done
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          STAMP(c3);
-          __syncthreads();                                                                 // (Y)
-        }
-      } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       STAMP(c3);
       __syncthreads();                                                                     // (Y)
-      }
       STAMP(c4);
 #ifdef VFML_TAPX_STAMPS
       sX += c1 - c0; sM += c2 - c1; sW += c3 - c2; sY += c4 - c3;
@@ -378,11 +332,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
 #endif
 }
 
-template <int TM, int TN, int WM, int WN, int NM, bool BREG = false>
+template <int TM, int TN, int WM, int WN, int NM>
 int launch_tapx_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
   constexpr int NPA = (TBM + VFML_TAPX_KWMAX - 1 + 7) / 8;
-  constexpr size_t stage = 2 * (size_t)NPA * 1024 + (BREG ? 0 : (size_t)TBN * 128) + 128;
+  constexpr size_t stage = 2 * (size_t)NPA * 1024 + (size_t)TBN * 128 + 128;
   constexpr size_t slab = (size_t)WM * 32 * (TBN + 4) * 4;
   constexpr size_t lds = stage > slab ? stage : slab;
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
@@ -390,7 +344,7 @@ int launch_tapx_k(SplitArgs& a, hipStream_t s) {
   a.ntiles = (a.cout + TBN - 1) / TBN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_tapx_kernel<TM, TN, WM, WN, NM, BREG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_tapx_kernel<TM, TN, WM, WN, NM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -398,7 +352,7 @@ int launch_tapx_k(SplitArgs& a, hipStream_t s) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_gemm_tapx_kernel<TM, TN, WM, WN, NM, BREG>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_tapx_kernel<TM, TN, WM, WN, NM>), dim3(a.mtiles * a.ntiles), dim3(256), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
@@ -425,11 +379,7 @@ int vfml_detail::tapx_cfg(const SplitArgs& a, int cfg, bool forced) {
 
 int vfml_detail::launch_tapx(SplitArgs& a, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 3222: {
-      static const int breg = getenv("VFML_TAPX_BREG") ? atoi(getenv("VFML_TAPX_BREG")) : 0;     // experiment
-      if (breg) return a.nm == 5 ? launch_tapx_k<3, 2, 2, 2, 5, true>(a, s) : launch_tapx_k<3, 2, 2, 2, 3, true>(a, s);
-      return a.nm == 5 ? launch_tapx_k<3, 2, 2, 2, 5>(a, s) : launch_tapx_k<3, 2, 2, 2, 3>(a, s);
-    }
+    case 3222: return a.nm == 5 ? launch_tapx_k<3, 2, 2, 2, 5>(a, s) : launch_tapx_k<3, 2, 2, 2, 3>(a, s);
     case 2322: return a.nm == 5 ? launch_tapx_k<2, 3, 2, 2, 5>(a, s) : launch_tapx_k<2, 3, 2, 2, 3>(a, s);
     case 2241: return a.nm == 5 ? launch_tapx_k<2, 2, 4, 1, 5>(a, s) : launch_tapx_k<2, 2, 4, 1, 3>(a, s);
     case 2341: return a.nm == 5 ? launch_tapx_k<2, 3, 4, 1, 5>(a, s) : launch_tapx_k<2, 3, 4, 1, 3>(a, s);

@@ -222,6 +222,25 @@ __global__ void coords_init_kernel(f32x4* __restrict__ coords, int h, int w, int
   }
 }
 
+// out[p] = bias + sum of the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3)
+__global__ void tapsum3x3_kernel(const float* __restrict__ t, int ld, const float* __restrict__ bias, int h, int w,
+                                 int64_t total, f32x4* __restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % w), y = (int)((p / w) % h);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (bias) s = f32x4{bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w)
+          s = s + *reinterpret_cast<const f32x4*>(t + (p + (int64_t)(ky - 1) * w + (kx - 1)) * ld + (ky * 3 + kx) * 4);
+      }
+    out[p] = s;
+  }
+}
+
 __global__ void coords_update_kernel(f32x4* __restrict__ coords, const f32x4* __restrict__ delta, int h, int w,
                                      int64_t total, float* __restrict__ fa, int lda, float* __restrict__ fb, int ldb,
                                      int b16) {
@@ -501,6 +520,16 @@ extern "C" int vfml_coords_update(float* coords1, const float* delta, int n, int
                      reinterpret_cast<hipStream_t>(stream), (f32x4*)coords1, (const f32x4*)delta, h, w, total, flow_a,
                      ld_a, flow_b, ld_b, fmt_b == VFML_FMT_S16 ? 1 : 0);
   return vfml_check_launch("vfml_coords_update");
+}
+
+extern "C" int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, void* stream) {
+  VFML_REQUIRE(t && out && n > 0 && h > 0 && w > 0, "vfml_tapsum3x3: bad argument");
+  VFML_REQUIRE(ld_t >= 36 && ld_t % 4 == 0 && vfml_aligned16(t) && vfml_aligned16(out),
+               "vfml_tapsum3x3: ld_t must be a multiple of 4 and >= 36, t and out 16-byte aligned");
+  const int64_t total = (int64_t)n * h * w;
+  hipLaunchKernelGGL(tapsum3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
+                     ld_t, bias, h, w, total, (f32x4*)out);
+  return vfml_check_launch("vfml_tapsum3x3");
 }
 
 extern "C" int vfml_flow_lod(const float* flow, int h, int w, float* out, void* stream) {

@@ -118,6 +118,7 @@ def lib():
                                             c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+    L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
     L.vfml_flow_lod.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
@@ -139,7 +140,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
-    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init",
+    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3",
     "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -497,6 +498,12 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
 
 def coords_init(coords1, n, h, w):
     _check(lib().vfml_coords_init(_ptr(_dev(coords1)), n, h, w, _stream()), "vfml_coords_init")
+
+
+def tapsum3x3(t, ld_t, bias, n, h, w, out):
+    """out[p][0:4] = bias + the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3)."""
+    _check(lib().vfml_tapsum3x3(_ptr(_dev(t)), ld_t, _ptr(bias) if bias is not None else None, n, h, w, _ptr(_dev(out)),
+                                _stream()), "vfml_tapsum3x3")
 
 
 def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None, ld_b=0, flow_b_off=0,

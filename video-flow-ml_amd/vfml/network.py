@@ -98,6 +98,7 @@ class MOFNetHIP(_Holder):
         if self._packed is not None and self._packed_key == key:
             return self._packed
         P, cblock_names, cb64_names = {}, set(), set()
+        cout_packed = {}       # layers whose packed matrix has another row count than their bias
 
         def block_of(layer, c0, ctot, cout):
             """K-axis block of a split-row layer's weight planes: 64 channels where the layer runs one MFMA per product
@@ -123,6 +124,12 @@ class MOFNetHIP(_Holder):
                 wp[:, :cor] = w[:, sel]
                 wp[:, cor_p:cor_p + cor] = w[:, base + sel]
                 w = wp
+            if (name.endswith(".flow_head.conv2") and split and cout == 4 and (kh, kw) == (3, 3)
+                    and not os.environ.get("VFML_NO_TAPSUM")):       # (A/B switch)
+                # 3x3 to four channels as a 1x1 to 36 (tap-major) + vfml_tapsum3x3: nine times fewer MFMA steps than a
+                # 3x3 convolution padded to a 32-column tile
+                w = w.permute(2, 3, 0, 1).reshape(36, cin, 1, 1).contiguous()
+                cout_packed[name] = 36
             if name.endswith(".tprop"):
                 # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
                 w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
@@ -165,12 +172,13 @@ class MOFNetHIP(_Holder):
             # split-f16 planes (hi, lo*2^11) of every [cout][K] matrix, made once per load
             with torch.cuda.device(device):
                 for name, (wflat, b) in list(P.items()):
-                    cout = self._cout_of[name] if name in self._cout_of else b.numel()
+                    cout = self._cout_of[name] if name in self._cout_of else cout_packed.get(name, b.numel())
                     sc = hip.SplitWeight.auto_scale(float(wflat.abs().max()))
                     sw = hip.SplitWeight(cout, wflat.numel() // cout, device).fill(wflat, scale=sc)
                     sw.order = (hip.KORDER_CBLOCK64 if name in cb64_names else
                                 hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP)
                     P[name] = (sw, b)
+        self._tapsum = bool(cout_packed)
         self._packed, self._packed_key = P, key
         self._graphs.clear()              # captured launches hold the old planes' addresses
         self._packed_serial += 1          # new weights: cached encoder outputs are stale
@@ -621,6 +629,7 @@ class MOFNetHIP(_Holder):
             fh = self._buf("fh", MP * 256, dev)
             flow4 = self._buf("flow4", MP * 4, dev)
             delta = self._buf("delta", MP * 4, dev)
+            fh_taps = self._buf("fh_taps", MP * 36, dev)
             coords1 = self._buf("coords1", MP * 4, dev)
 
             # ---- the update iterations + mask head + upsampling: a FIXED launch sequence for a given geometry,
@@ -703,8 +712,14 @@ class MOFNetHIP(_Holder):
                     hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.flow_head.conv1"))
                     wgt, b = P[f"{ub}.flow_head.conv2"]
-                    hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF,
-                               mfma=mf(f"{ub}.flow_head.conv2"))
+                    if self._tapsum:
+                        # 256 -> 4 over 3x3 as a 1x1 to 36 tap-major columns + the nine taps summed per pixel (_pack)
+                        hip.conv2d(fh, 256, 256, ng, h, w, wgt, None, 36, 1, 1, fh_taps, 36, in_fmt=AF,
+                                   mfma=mf(f"{ub}.flow_head.conv2"))
+                        hip.tapsum3x3(fh_taps, 36, b, ng, h, w, delta)
+                    else:
+                        hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF,
+                                   mfma=mf(f"{ub}.flow_head.conv2"))
                     hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
                                       flow_b_off=MF + 124, fmt_b=AF)
 
