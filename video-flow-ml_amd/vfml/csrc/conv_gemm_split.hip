@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
   // (every wave passed the loop's final barrier, so the staging buffers are free)
   acc_to_lds<TM, TN, LDC>(acc, sC, wm * (BM / WM), wn * (BN / WN), r, half);
   __syncthreads();
-  epilogue_rows<BN, NT>(a, sC, m0, n0, t);
+  if (!epilogue_rows_fast<BN, NT>(a, sC, m0, n0, t, BM, 32, 0)) epilogue_rows<BN, NT>(a, sC, m0, n0, t);
   if (a.stats_part) {
     // instance-norm statistics of the tile while it is in LDS: thread = (channel, row group), doubles like the
     // stand-alone pass; the value is the stored one (same expression as epilogue_rows, no addend / activation here)
@@ -938,7 +938,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           }
         }
         __syncthreads();
-        epilogue_rows<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
+        if (!epilogue_rows_fast<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32))
+          epilogue_rows<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
         if (a.stats_part) {
           // instance-norm statistics of the slab while it is in LDS (vfml_conv_desc.stats_part, split-row sources): the
           // slab's rows wb*32 .. wb*32+31 are the 32 consecutive output pixels from cur_m0 + wb*32*TM + i*32 on; one
@@ -1143,7 +1144,8 @@ __global__ __launch_bounds__((WM * WN + 1) * 64, 3) void conv_gemm_lw_kernel(con
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    epilogue_rows<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32);
+    if (!epilogue_rows_fast<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32))
+      epilogue_rows<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32);
   });
 }
 
@@ -1682,6 +1684,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   SplitArgs a;
   a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0; a.bhi = 0;
   a.stats_part = d->stats_part;
+  static const int no_fast_epi = getenv("VFML_NO_FAST_EPI") ? atoi(getenv("VFML_NO_FAST_EPI")) : 0;
+  a.fast_epi = !no_fast_epi;
   a.nm = (d->flags & VFML_CONV_MFMA1) ? 1 : (d->flags & VFML_CONV_MFMA2A) ? (bhi ? 1 : 4) : ((d->flags & VFML_CONV_MFMA2) || bhi) ? 2 : 3;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)

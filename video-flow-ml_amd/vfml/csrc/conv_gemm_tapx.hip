@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
       });
     });
     lds_barrier();
-    epilogue_rows<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32);
+    if (!epilogue_rows_fast<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32))
+      epilogue_rows<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32);
     if (a.stats_part) {
       // instance-norm statistics of the slab while it is in LDS (vfml_conv_desc.stats_part, as conv_gemm_dma_kernel): the
       // slab's rows wb*32 .. wb*32+31 are the 32 consecutive output pixels from m0 + wb*32*TM + i*32 on; one thread per

@@ -40,6 +40,7 @@ struct SplitArgs {
   int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
   double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
   int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
+  int fast_epi;                 // 0: the general epilogue routine everywhere (VFML_NO_FAST_EPI=1, A/B)
 };
 // conv_gemm_tapx.hip: the kernel that shares one activation stage between the taps of a filter row
 #define VFML_TAPX_KWMAX 5      // widest filter row it is built for
@@ -218,6 +219,112 @@ __device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* s
         }
       }
     }
+  }
+}
+
+// The same rows as epilogue_rows for the calls the update block makes all day: whole 8-channel units (the tile's columns
+// lie inside cout, 16-byte aligned operands), split-row aux operands, the epilogue kind a compile-time constant.  One
+// thread per (row, unit): two 16-byte LDS reads, 16-byte loads of the addend / aux units, the same expressions as
+// epilogue_rows (bit-identical results), two 16-byte stores.  ~3x fewer vector instructions than the general routine - an
+// epilogue shares its SIMD with the other resident workgroup's MFMA stream and takes ~10 cycles per vector instruction
+// there (profiles/r02_kernel_anatomy.md).  Returns false (nothing done) when the call is not of that shape.
+template <int EPI>
+__device__ __forceinline__ void epi_unit(f32x4 (&v)[2], const f32x4 (&x0)[2], const f32x4 (&x1)[2], bool lowhalf) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r = v[q][e];
+      if constexpr (EPI == VFML_EPI_RELU) r = fmaxf(r, 0.f);
+      else if constexpr (EPI == VFML_EPI_TANH) r = tanhf(r);
+      else if constexpr (EPI == VFML_EPI_SIGMOID) r = sigmoidf_(r);
+      else if constexpr (EPI == VFML_EPI_GRU_ZR) { r = sigmoidf_(r); r = lowhalf ? r : r * x0[q][e]; }
+      else if constexpr (EPI == VFML_EPI_GRU_Q) r = (1.f - x0[q][e]) * x1[q][e] + x0[q][e] * tanhf(r);
+      v[q][e] = r;
+    }
+}
+
+// the 8 channels of a split-row unit at float offset `off` from base (16 B of hi halves, 16 B of lo halves)
+__device__ __forceinline__ void load_unit16(const float* base, int64_t off, f32x4 (&x)[2]) {
+  const h16x8 h = *reinterpret_cast<const h16x8*>(base + off);
+  const h16x8 l = *reinterpret_cast<const h16x8*>(base + off + 4);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e >> 2][e & 3] = (float)h[e] + (float)l[e];
+}
+
+template <int BN, int NT, int EPI>
+__device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const float* sC, int m0, int n0, int t, int nrows,
+                                                     int rstride, int roff) {
+  constexpr int LDC = BN + 4;
+  constexpr int C8 = BN / 8;
+  constexpr int RPP = NT / C8;
+  const int c8 = t % C8;
+  const int gcol = n0 + c8 * 8;
+  if (gcol >= a.cout) return;
+  const bool whole = gcol + 8 <= a.cout;        // cout % 4 == 0: the last unit may be its first quad only
+  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (a.bias) {
+    bias4[0] = *reinterpret_cast<const f32x4*>(a.bias + gcol);
+    if (whole) bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + gcol + 4);
+  }
+  const bool lowhalf = gcol < a.split;          // split is a multiple of 8 here: a unit never straddles it
+  for (int row = t / C8; row < nrows; row += RPP) {
+    const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
+    if (grow >= a.M) continue;
+    f32x4 v[2], add4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, x0[2], x1[2];
+    v[0] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8]);
+    v[1] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4]);
+    if (a.addend) {
+      add4[0] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol);
+      if (whole) add4[1] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol + 4);
+    }
+    if constexpr (EPI == VFML_EPI_GRU_ZR) {
+      if (!lowhalf) load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol - a.split, x0);
+    }
+    if constexpr (EPI == VFML_EPI_GRU_Q) {
+      load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol, x0);
+      load_unit16(a.aux1, (int64_t)grow * a.ld_aux1 + gcol, x1);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] = (v[q][e] * a.w_inv + add4[q][e] + bias4[q][e]) * a.out_scale;
+    epi_unit<EPI>(v, x0, x1, lowhalf);
+    if (a.out16) {
+      U8 hi, lo;
+      split4(v[0], hi, lo, 0);
+      split4(v[1], hi, lo, 4);
+      float* u = a.out + (int64_t)grow * a.ldo + gcol;
+      if (whole) {
+        *reinterpret_cast<h16x8*>(u) = hi.v;
+        *reinterpret_cast<h16x8*>(u + 4) = lo.v;
+      } else {       // the unit's second quad belongs to someone else (the motion features' flow channels)
+        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+        *reinterpret_cast<uint2*>(u + 4) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+      }
+    } else {
+      float* o = a.out + (int64_t)grow * a.ldo + gcol;
+      *reinterpret_cast<f32x4*>(o) = v[0];
+      if (whole) *reinterpret_cast<f32x4*>(o + 4) = v[1];
+    }
+  }
+}
+
+template <int BN, int NT>
+__device__ __forceinline__ bool epilogue_rows_fast(const SplitArgs& a, const float* sC, int m0, int n0, int t, int nrows,
+                                                   int rstride, int roff) {
+  // (uniform over the workgroup: every thread takes the same route)
+  const bool gru = a.epilogue == VFML_EPI_GRU_ZR || a.epilogue == VFML_EPI_GRU_Q;
+  if (!(a.fast_epi && a.vec_ok && a.cout % 4 == 0 && (!gru || (a.aux16 && a.split % 8 == 0 && a.cout % 8 == 0)) &&
+        (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15u) == 0) && a.epilogue != VFML_EPI_TANH_RELU &&
+        a.epilogue != VFML_EPI_ADD_AUX))
+    return false;
+  switch (a.epilogue) {
+    case VFML_EPI_NONE: epilogue_rows_fast_k<BN, NT, VFML_EPI_NONE>(a, sC, m0, n0, t, nrows, rstride, roff); return true;
+    case VFML_EPI_RELU: epilogue_rows_fast_k<BN, NT, VFML_EPI_RELU>(a, sC, m0, n0, t, nrows, rstride, roff); return true;
+    case VFML_EPI_GRU_ZR: epilogue_rows_fast_k<BN, NT, VFML_EPI_GRU_ZR>(a, sC, m0, n0, t, nrows, rstride, roff); return true;
+    case VFML_EPI_GRU_Q: epilogue_rows_fast_k<BN, NT, VFML_EPI_GRU_Q>(a, sC, m0, n0, t, nrows, rstride, roff); return true;
+    default: return false;
   }
 }
 
