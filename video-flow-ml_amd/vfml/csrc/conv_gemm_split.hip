@@ -1249,15 +1249,8 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     if (a.nm == 1) return launch_dma_k<TM, TN, WM, WN, false, false, false, 1, true>(a, s);
     return launch_dma_k<TM, TN, WM, WN, false, false, false, 3, true>(a, s);
   }
-  // 8-wave shapes (one workgroup per CU; VFML_DMA_TILE experiments): full precision only
-  if (a.nm == 5) {
-    vfml_set_error("vfml_conv2d_split: no 64-channel-step variant for the 8-wave experiment tiles");
-    return 1;
-  }
-  a.nm = 3;
-  if (a.fastk) return launch_dma_k<TM, TN, WM, WN, false, true, false, 3, true>(a, s);
-  a.abias = 0;
-  return launch_dma_k<TM, TN, WM, WN, false, false>(a, s);
+  vfml_set_error("vfml_conv2d_split: no such tile shape");
+  return 1;
 }
 
 template <int BN, int WM, int WN, bool BIGC, bool IN16, int NM>
@@ -1827,11 +1820,10 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
       switch (cfg) {
         case 3222: return launch_dma<3, 2, 2, 2>(a, s);   // 192 x 128, 2 workgroups per CU
         case 2322: return launch_dma<2, 3, 2, 2>(a, s);   // 128 x 192
-        case 2242: return launch_dma<2, 2, 4, 2>(a, s);   // 256 x 128, 8 waves
-        case 3224: return launch_dma<3, 2, 2, 4>(a, s);   // 192 x 256, 8 waves
-        case 4224: return launch_dma<4, 2, 2, 4>(a, s);   // 256 x 256, 8 waves
         case 2122: return launch_dma<2, 1, 2, 2>(a, s);   // 128 x 64
         case 1141: return launch_dma<1, 1, 4, 1>(a, s);   // 128 x 32
+        // (the 8-wave shapes of round 1 - 256 x 128, 192 x 256, 256 x 256, one workgroup per CU - measured slower and are
+        // no longer built)
         case 2241: case 2341: return launch_dma<2, 1, 2, 2>(a, s);   // (forced shared-stage shapes on a call that kernel does not take)
         default: return launch_dma<2, 2, 2, 2>(a, s);
       }
