@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
-  static_assert(!(MF16 && PERSIST && !FASTK), "the 16x16x32 GEMM form exists for the uniform-step loader only");
+  static_assert(!(MF16 && PERSIST), "the persistent GEMM form runs 32x32x16 MFMAs (its 16x16x32 epilogue branches below are not maintained)");
   // NM == 5 (H64): one MFMA per product like NM == 1, and a K step covers 64 channels of hi halves only: a staged row's 128
   // bytes are the hi halves of eight 8-channel units (fetched at a 32-byte stride from the split-row source; the weight
   // row's are contiguous in its hi plane) - no lane fetches a lo half, half the steps, barriers and LDS-DMA
@@ -629,9 +629,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           if constexpr (!AHI) al = *reinterpret_cast<const h16x8*>(base + (aoff4 ^ 16) + i * 2048);
           static_for<2 * TN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc4[i][j], 0, 0, 0);
-            if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc4[i][j], 0, 0, 0);
-            if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc4[i][j], 0, 0, 0);
+            // (the weight fragment is the FIRST operand: a lane's accumulator quad is then four consecutive output
+            // channels of one pixel - D[cout 4 (lane >> 4) + e][pixel lane & 15] - which is what the epilogue stores)
+            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc4[i][j], 0, 0, 0);
+            if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, acc4[i][j], 0, 0, 0);
+            if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, acc4[i][j], 0, 0, 0);
 #ifndef VFML_ISSUE_DIV
 #define VFML_ISSUE_DIV 2      // the next step's pieces go out behind the first 1/DIV of this step's MFMA groups
 #endif
@@ -906,25 +908,23 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       }
       stores_behind = true;
     } else {
-      // Epilogue in TM slabs: slab i holds block row i of every wave (WM*32 rows x TBN) in LDS.
+      // Epilogue in TM slabs: slab i holds block row i of every wave (WM*32 rows x TBN) in LDS.  (Straight from the
+      // accumulators - a lane holds four consecutive channels of a pixel - with 8-byte loads and stores, no LDS: measured
+      // 0.7 ms per 1080p field slower than the rows below.)
+      {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         __syncthreads();     // every wave is done with the stage buffers / with the previous slab
         if constexpr (MF16) {
-          // 16 x 16 tiles: column = lane & 15, row = 4 * (lane >> 4) + register; block row i = tile rows 2i, 2i + 1
-          // (i is the index of the enclosing slab loop: made a compile-time constant through static_for below)
+          // 16 x 16 tiles: a lane's quad = pixel row lane & 15, output channels 4 (lane >> 4) .. + 3; block row i = tile
+          // rows 2i, 2i + 1 (i is the index of the enclosing slab loop: a compile-time constant through static_for)
           static_for<2>([&](auto tc) {
             constexpr int t2 = decltype(tc)::value;
             static_for<2 * TN>([&](auto jc) {
               constexpr int j = decltype(jc)::value;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int row = wm * 32 + t2 * 16 + 4 * u4 + e;
-                const int col = wn * (32 * TN) + j * 16 + r4;
-                float v = 0.f;
-                static_for<TM>([&](auto ii) { if (decltype(ii)::value == i) v = acc4[2 * decltype(ii)::value + t2][j][e]; });
-                sC[row * LDC + col] = v;
-              }
+              f32x4 v = {0.f, 0.f, 0.f, 0.f};
+              static_for<TM>([&](auto ii) { if (decltype(ii)::value == i) v = acc4[2 * decltype(ii)::value + t2][j]; });
+              *reinterpret_cast<f32x4*>(&sC[(wm * 32 + t2 * 16 + r4) * LDC + wn * (32 * TN) + j * 16 + 4 * u4]) = v;
             });
           });
         } else {
@@ -938,6 +938,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           }
         }
         __syncthreads();
+        // (what the fast rows take, the 16x16x32 forms have already written straight from their accumulators)
         if (!epilogue_rows_fast<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32))
           epilogue_rows<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
         if (a.stats_part) {
@@ -962,6 +963,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             }
           }
         }
+      }
       }
     }
     if (!PERSIST || next >= tile_end) break;
@@ -1677,8 +1679,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   SplitArgs a;
   a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0; a.bhi = 0;
   a.stats_part = d->stats_part;
-  static const int no_fast_epi = getenv("VFML_NO_FAST_EPI") ? atoi(getenv("VFML_NO_FAST_EPI")) : 0;
-  a.fast_epi = !no_fast_epi;
+  static const int fast_epi = getenv("VFML_FAST_EPI") ? atoi(getenv("VFML_FAST_EPI")) : 1;
+  a.fast_epi = fast_epi;
   a.nm = (d->flags & VFML_CONV_MFMA1) ? 1 : (d->flags & VFML_CONV_MFMA2A) ? (bhi ? 1 : 4) : ((d->flags & VFML_CONV_MFMA2) || bhi) ? 2 : 3;
   a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0;
   // one buffer descriptor serves both sources: they must lie in one allocation (within 1 GiB)

@@ -236,12 +236,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
         static_for<2 * TN>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           // (term-major order within the tile row - consecutive MFMAs on different accumulators - measured 2-5 % slower)
-          acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[j], acc4[i][j], 0, 0, 0);
+          // (the weight fragment is the FIRST operand: a lane's accumulator quad is then four consecutive output channels
+          // of one pixel - D[cout 4 (lane >> 4) + e][pixel lane & 15] - which is what the epilogue stores)
+          acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[j], a0, acc4[i][j], 0, 0, 0);
           if constexpr (H64) {
-            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[j], acc4[i][j], 0, 0, 0);
+            acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], a1, acc4[i][j], 0, 0, 0);
           } else {
-            if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1[j], acc4[i][j], 0, 0, 0);
-            if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0[j], acc4[i][j], 0, 0, 0);
+            if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], a0, acc4[i][j], 0, 0, 0);
+            if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0[j], a1, acc4[i][j], 0, 0, 0);
           }
           // behind the first groups: the next step's weight pieces, then this step's share of the next activation stage
           constexpr int g = i * (2 * TN) + j;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
     vfml_tapx_stamps[wave * 8 + 6] = __builtin_amdgcn_s_memrealtime() - k0r;   // the same interval at the constant 100 MHz
   }
 #endif
-  // Epilogue in TM slabs: slab i holds block row i of every wave (WM*32 rows x TBN) in LDS.
+  // Epilogue in TM slabs through LDS: slab i holds block row i of every wave (WM*32 rows x TBN).
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     // (LDS hazards only: a __syncthreads() would also wait for the previous slab's global stores to be acknowledged)
@@ -287,14 +289,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
       constexpr int t2 = decltype(tc)::value;
       static_for<2 * TN>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = wm * 32 + t2 * 16 + 4 * u4 + e;
-          const int col = wn * (32 * TN) + j * 16 + r4;
-          float v = 0.f;
-          static_for<TM>([&](auto ii) { if (decltype(ii)::value == i) v = acc4[2 * decltype(ii)::value + t2][j][e]; });
-          sC[row * LDC + col] = v;
-        }
+        // a lane's quad = pixel row r4 of the 16-row tile, output channels 4 u4 .. 4 u4 + 3 of the 16-column tile
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        static_for<TM>([&](auto ii) { if (decltype(ii)::value == i) v = acc4[2 * decltype(ii)::value + t2][j]; });
+        *reinterpret_cast<f32x4*>(&sC[(wm * 32 + t2 * 16 + r4) * LDC + wn * (32 * TN) + j * 16 + 4 * u4]) = v;
       });
     });
     lds_barrier();

@@ -40,7 +40,7 @@ struct SplitArgs {
   int bhi;                      // LDS-DMA GEMM form: the weight operand is one plain f16 plane (no lo plane)
   double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
   int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
-  int fast_epi;                 // 0: the general epilogue routine everywhere (VFML_NO_FAST_EPI=1, A/B)
+  int fast_epi;                 // 0: the general epilogue routine everywhere (VFML_FAST_EPI=0, A/B)
 };
 // conv_gemm_tapx.hip: the kernel that shares one activation stage between the taps of a filter row
 #define VFML_TAPX_KWMAX 5      // widest filter row it is built for
@@ -268,45 +268,61 @@ __device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const f
     if (whole) bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + gcol + 4);
   }
   const bool lowhalf = gcol < a.split;          // split is a multiple of 8 here: a unit never straddles it
-  for (int row = t / C8; row < nrows; row += RPP) {
+  // The addend / aux units of a row are requested one row ahead, BEFORE the previous row's stores: vmcnt counts in order,
+  // a load issued behind a store could only be waited for together with the store's acknowledgement.
+  struct RowOps {
+    f32x4 add[2], x0[2], x1[2];
+  };
+  auto load_row = [&](int row, RowOps& o) {
     const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
-    if (grow >= a.M) continue;
-    f32x4 v[2], add4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, x0[2], x1[2];
-    v[0] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8]);
-    v[1] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4]);
+    o.add[0] = o.add[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o.x0[0] = o.x0[1] = o.x1[0] = o.x1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row >= nrows || grow >= a.M) return;
     if (a.addend) {
-      add4[0] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol);
-      if (whole) add4[1] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol + 4);
+      o.add[0] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol);
+      if (whole) o.add[1] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol + 4);
     }
     if constexpr (EPI == VFML_EPI_GRU_ZR) {
-      if (!lowhalf) load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol - a.split, x0);
+      if (!lowhalf) load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol - a.split, o.x0);
     }
     if constexpr (EPI == VFML_EPI_GRU_Q) {
-      load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol, x0);
-      load_unit16(a.aux1, (int64_t)grow * a.ld_aux1 + gcol, x1);
+      load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol, o.x0);
+      load_unit16(a.aux1, (int64_t)grow * a.ld_aux1 + gcol, o.x1);
     }
+  };
+  RowOps cur, nxt;
+  load_row(t / C8, cur);
+  for (int row = t / C8; row < nrows; row += RPP) {
+    const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
+    load_row(row + RPP, nxt);
+    if (grow < a.M) {
+      f32x4 v[2];
+      v[0] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8]);
+      v[1] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4]);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[q][e] = (v[q][e] * a.w_inv + add4[q][e] + bias4[q][e]) * a.out_scale;
-    epi_unit<EPI>(v, x0, x1, lowhalf);
-    if (a.out16) {
-      U8 hi, lo;
-      split4(v[0], hi, lo, 0);
-      split4(v[1], hi, lo, 4);
-      float* u = a.out + (int64_t)grow * a.ldo + gcol;
-      if (whole) {
-        *reinterpret_cast<h16x8*>(u) = hi.v;
-        *reinterpret_cast<h16x8*>(u + 4) = lo.v;
-      } else {       // the unit's second quad belongs to someone else (the motion features' flow channels)
-        *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
-        *reinterpret_cast<uint2*>(u + 4) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+        for (int e = 0; e < 4; ++e) v[q][e] = (v[q][e] * a.w_inv + cur.add[q][e] + bias4[q][e]) * a.out_scale;
+      epi_unit<EPI>(v, cur.x0, cur.x1, lowhalf);
+      if (a.out16) {
+        U8 hi, lo;
+        split4(v[0], hi, lo, 0);
+        split4(v[1], hi, lo, 4);
+        float* u = a.out + (int64_t)grow * a.ldo + gcol;
+        if (whole) {
+          *reinterpret_cast<h16x8*>(u) = hi.v;
+          *reinterpret_cast<h16x8*>(u + 4) = lo.v;
+        } else {       // the unit's second quad belongs to someone else (the motion features' flow channels)
+          *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+          *reinterpret_cast<uint2*>(u + 4) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+        }
+      } else {
+        float* o = a.out + (int64_t)grow * a.ldo + gcol;
+        *reinterpret_cast<f32x4*>(o) = v[0];
+        if (whole) *reinterpret_cast<f32x4*>(o + 4) = v[1];
       }
-    } else {
-      float* o = a.out + (int64_t)grow * a.ldo + gcol;
-      *reinterpret_cast<f32x4*>(o) = v[0];
-      if (whole) *reinterpret_cast<f32x4*>(o + 4) = v[1];
     }
+    cur = nxt;
   }
 }
 
