@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f16x3", "f16x2", "f16", "mixed", "f32"],
                     help="arithmetic of the engine (vfml/cfg.py); default: f16x3, and f16 for bof720p (BASELINE config 5 "
                          "is quoted in fp16)")
+    ap.add_argument("--corr-volume", default=None, choices=["f32", "f16"],
+                    help="storage of the correlation pyramids (vfml/cfg.py corr_volume; default f32; f16 is the opt-in "
+                         "half-size volume, ~1e-4 px against the oracle at 1080p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the separate per-launch timing pass")
     ap.add_argument("--full-output", action="store_true",
@@ -98,6 +101,8 @@ def main():
     precision = args.precision or {"bof720p": "f16", "mof1080p": "mixed"}.get(args.workload)
     if precision and args.workload != "memflow1080p":
         os.environ["VFML_PRECISION"] = precision  # read by VideoFlowCore
+    if args.corr_volume:
+        os.environ["VFML_CORR_VOLUME"] = args.corr_volume
     from vfml import dist as vdist, get_cfg, hip
     from vfml.runner import ClipFeeder, run_sharded
     from vfml.synth import synthetic_clip
@@ -272,6 +277,7 @@ def main():
                                + f" seq_len={T} {args.width}x{args.height} synthetic clip, decoder_depth={depth}, "
                                  f"seeded weights",
                    "fields_per_gpu": K, "clip_frames": len(clip_np), "parallelism": f"frames-dp{world}",
+                   "corr_volume": getattr(core.cfg, "corr_volume", "f32"),
                    "inputs": "uint8 frames in host memory (uploaded inside the timed region through a pinned ring)",
                    "outputs": "[H,W,2] f32 fields in rank-0 host memory (pinned D2H of field i under field i+1"
                               + ("; ranks' fields streamed to rank 0 in chunked RCCL gathers)" if world > 1 else ")"),

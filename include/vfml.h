@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 20
+#define VFML_ABI_VERSION 21
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -48,7 +48,12 @@ enum {
  *                 split-f16 MFMA kernel, written once by the producer instead of being re-derived by
  *                 every consumer.  Channel offsets / counts / ld are multiples of 8 (a producer may
  *                 write a 4-channel half unit), bases 32-byte aligned. */
-enum { VFML_FMT_F32 = 0, VFML_FMT_S16 = 1 };
+enum { VFML_FMT_F32 = 0, VFML_FMT_S16 = 1,
+/* one f16 (round to nearest) per element, row pitches counted in ELEMENTS: only as the output of vfml_conv2d_split's GEMM
+ * form (out and out_t: the correlation volumes) and as `vol_fmt` of the lookups that read them back - the opt-in half-size
+ * correlation pyramid (cfg.corr_volume = "f16": half the store bytes of the volume GEMMs, half the pyramid memory, fewer
+ * sectors per gathered window; the volume's values then carry 11 bits) */
+       VFML_FMT_F16 = 2 };
 
 /* Implicit-GEMM 2-D convolution / plain GEMM on the f32 matrix cores.
  *   out[p][co] = epi( sum_{ky,kx,ci} in(p; ky,kx)[ci] * w[co][ky][kx][ci] + bias[co] )
@@ -217,9 +222,11 @@ int vfml_avgpool2x2(const float* x, int n, int h, int w, int c, float* out, void
  * Replaces: F.grid_sample(align_corners=True) x levels. */
 int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl,
                      const int32_t* ld, int levels, int radius, int nmaps, int q_per_map,
-                     const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, void* stream);
+                     const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
 /* out_fmt VFML_FMT_S16: channels are written as split rows; the channel count is rounded up to a
- * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0). */
+ * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0).
+ * vol_fmt VFML_FMT_F32, or VFML_FMT_F16: the pyramids hold one f16 per element (ld in elements; radius 3 or 4, at most four
+ * levels). */
 
 /* The same lookup with the pyramid pointers read from a DEVICE table at run time: table[m * levels + l] is what
  * pyr[m * levels + l] is above.  A launch recorded in a HIP graph (the update iterations of a field are a fixed launch
@@ -228,7 +235,7 @@ int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* 
  * kernel arguments: no host buffer has to outlive the call). */
 int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                               int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
-                              float* out, int ld_out, int out_fmt, void* stream);
+                              float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
 int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream);
 
 /* A 3x3 "same" convolution with FOUR output channels as a 1x1 convolution to 36 (tap-major: column (ky*3+kx)*4 + o holds

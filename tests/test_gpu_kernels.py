@@ -945,3 +945,81 @@ def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
     assert rel_err(got, ref) < 2e-6
     with pytest.raises(RuntimeError, match="ld_t"):
         hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)
+
+
+def _as_f32_storage(half_tensor):
+    """A float16 tensor's bytes as the float32 buffer the ctypes wrappers take (even element count)."""
+    return half_tensor.contiguous().view(torch.float32)
+
+
+def test_gemm_form_writes_f16_volumes(gpu):
+    """VFML_FMT_F16 out / out_t of the GEMM form: every element is the round-to-nearest f16 of what the f32 form stores,
+    ragged tiles in both directions, nothing written outside; narrower than 1024 columns too (the form is forced); the
+    other forms refuse the format."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(77)
+    D = 256
+
+    def rows(f):
+        t = torch.empty(f.numel(), device=gpu)
+        hip.to_s16((f * 16.0).cuda().reshape(-1), f.shape[0], D, D, t, D)
+        return t
+
+    def planes(f):
+        return hip.SplitWeight(f.shape[0], D, torch.device("cuda")).fill(f.cuda().reshape(-1).contiguous(), scale=16.0)
+
+    for P, S, dual in ((1300, 1412, True), (520, 480, False)):
+        f1, f2 = torch.randn(P, D, generator=g), torch.randn(S, D, generator=g)
+        ld, ldt = (S + 31) // 32 * 32, (P + 31) // 32 * 32
+        out32 = torch.zeros(P * ld, device=gpu)
+        hip.conv2d(rows(f1), D, D, 1, 1, P, planes(f2), None, S, 1, 1, out32, ld, out_scale=1.0 / 256.0, in_fmt=hip.FMT_S16)
+        if S < 1024:     # (the f32 call of this width went through the convolution form: same sums up to rounding)
+            ref = (f1.double() @ f2.double().t() / 16.0).float()
+            assert rel_err(out32.view(P, ld)[:, :S].cpu(), ref) < CONV_TOL["f16x3"]
+        out16 = torch.full((P * ld,), 7.0, dtype=torch.float16, device=gpu)
+        out16_t = torch.full((S * ldt,), 9.0, dtype=torch.float16, device=gpu)
+        hip.conv2d(rows(f1), D, D, 1, 1, P, planes(f2), None, S, 1, 1, _as_f32_storage(out16), ld, out_scale=1.0 / 256.0,
+                   in_fmt=hip.FMT_S16, out_fmt=hip.FMT_F16, out_t=_as_f32_storage(out16_t) if dual else None,
+                   ld_out_t=ldt if dual else 0)
+        got = out16.view(P, ld)
+        if S >= 1024:
+            assert torch.equal(got[:, :S], out32.view(P, ld)[:, :S].half())
+        else:
+            assert rel_err(got[:, :S].float().cpu(), out32.view(P, ld)[:, :S].cpu()) < 1e-3
+        assert (got[:, S:] == 7.0).all()
+        if dual:
+            gt = out16_t.view(S, ldt)
+            assert torch.equal(gt[:, :P], got[:, :S].t())
+            assert (gt[:, P:] == 9.0).all()
+    with pytest.raises(RuntimeError, match="VFML_FMT_F16"):         # a 3x3 convolution cannot write it
+        x = torch.zeros(64 * 64, device=gpu)
+        w3 = hip.SplitWeight(64, 9 * 64, torch.device("cuda")).fill(torch.zeros(64 * 9 * 64, device=gpu))
+        hip.conv2d(x, 64, 64, 1, 8, 8, w3, None, 64, 3, 3, torch.zeros(64 * 64, device=gpu), 64, pad_h=1, pad_w=1,
+                   in_fmt=hip.FMT_S16, out_fmt=hip.FMT_F16)
+
+
+@pytest.mark.parametrize("radius,levels", [(4, 4), (3, 3)])
+def test_corr_lookup_reads_f16_volumes(gpu, radius, levels):
+    """vol_fmt VFML_FMT_F16: the lookup over a pyramid of f16 values == the lookup over the same values widened to f32
+    (same arithmetic on the same numbers: bit-identical), in both output formats."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(5 + radius)
+    h, w = 24, 40
+    P = h * w
+    hl = [h >> l for l in range(levels)]
+    wl = [w >> l for l in range(levels)]
+    ld = [(a * b + 31) // 32 * 32 for a, b in zip(hl, wl)]
+    vol16 = [torch.randn(P * l, generator=g).half().cuda() for l in ld]
+    vol32 = [v.float() for v in vol16]
+    coords = (torch.rand(P, 4, generator=g) * torch.tensor([w + 6.0, h + 6.0, w, h]) - 3.0).cuda().reshape(-1)
+    nch = levels * (2 * radius + 1) ** 2
+    ldo = (nch + 7) // 8 * 8
+    for fmt in (hip.FMT_F32, hip.FMT_S16):
+        a = torch.zeros(P * ldo, device=gpu)
+        b = torch.zeros(P * ldo, device=gpu)
+        hip.corr_lookup(vol32, hl, wl, ld, radius, P, coords, 0, 4, a, 0, ldo, out_fmt=fmt)
+        hip.corr_lookup([_as_f32_storage(v) for v in vol16], hl, wl, ld, radius, P, coords, 0, 4, b, 0, ldo, out_fmt=fmt,
+                        vol_fmt=hip.FMT_F16)
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="vol_fmt"):
+        hip.corr_lookup([_as_f32_storage(v) for v in vol16], hl, wl, ld, 2, P, coords, 0, 4, a, 0, ldo, vol_fmt=hip.FMT_F16)

@@ -51,6 +51,8 @@ class VideoFlowCore:
             if self.precision == "mixed":
                 from vfml.cfg import DEFAULT_MIXED_PLAN
                 cfg.mfma_plan = dict(self.mfma_plan if self.mfma_plan is not None else DEFAULT_MIXED_PLAN)
+        if os.environ.get("VFML_CORR_VOLUME"):     # 'f16': half-size correlation pyramids (vfml/cfg.py corr_volume)
+            cfg.corr_volume = os.environ["VFML_CORR_VOLUME"]
         if not os.path.exists(model_path):
             raise FileNotFoundError(f"VideoFlow model weights not found: {model_path}")
         self.cfg = cfg

@@ -60,6 +60,12 @@ def get_cfg():
         #   'f32'   exact fp32 on the f32 matrix cores (v_mfma_f32_32x32x2_f32), 5.3x slower peak
         precision="f16x3",
         mfma_plan=None,
+        # storage of the correlation pyramids: 'f32', or 'f16' (opt-in; VFML_CORR_VOLUME=f16): one round-to-nearest f16 per
+        # correlation value - half the store bytes of the volume GEMMs, half the pyramid memory (17 instead of 33 GB at
+        # 1080p seq 5), fewer sectors per gathered window; the values the motion encoder sees then carry 11 bits (1080p:
+        # mean EPE ~1e-4 px against the oracle instead of ~1e-5: inside the 1e-3 contract, outside the mixed plan's 1e-4
+        # budget, hence not a default)
+        corr_volume="f32",
         # the update iterations of a field as one replayed HIP graph (None: on unless VFML_GRAPH=0; results identical)
         use_graph=None,
     )

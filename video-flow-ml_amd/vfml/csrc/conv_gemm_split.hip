@@ -365,8 +365,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
 // piece) map of a fragment read differs, so the bank swizzle of the LDS image does too (swz16 below); the
 // accumulators are 16 x 16 tiles (4 registers each).  Not built for the persistent GEMM form.
 
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false, bool H16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gemm_dma_kernel(const SplitArgs a) {
+  static_assert(!H16 || PERSIST, "VFML_FMT_F16 outputs (H16) exist in the persistent GEMM form only");
   static_assert(!(MF16 && PERSIST), "the persistent GEMM form runs 32x32x16 MFMAs (its 16x16x32 epilogue branches below are not maintained)");
   // NM == 5 (H64): one MFMA per product like NM == 1, and a K step covers 64 channels of hi halves only: a staged row's 128
   // bytes are the hi halves of eight 8-channel units (fetched at a 32-byte stride from the split-row source; the weight
@@ -811,16 +812,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       // out-of-range offset, so every store instruction is issued (the relaxed vmcnt counts on NSTORE).
       const int rows_valid = a.M - cur_m0 < TBM ? a.M - cur_m0 : TBM;
       const int cols_valid = a.cout - cur_n0 < TBN ? a.cout - cur_n0 : TBN;
-      float* tbase = a.out + (int64_t)cur_m0 * a.ldo + cur_n0;
+      // (out_h16: VFML_FMT_F16 outputs - one f16 per element, 8-byte stores of four; same store count, half the bytes)
+      constexpr int ES = H16 ? 2 : 4;
+      char* tbase = reinterpret_cast<char*>(a.out) + ((int64_t)cur_m0 * a.ldo + cur_n0) * ES;
       const __amdgpu_buffer_rsrc_t ro =
-          __builtin_amdgcn_make_buffer_rsrc(tbase, 0, ((rows_valid - 1) * a.ldo + cols_valid) * 4, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(tbase, 0, ((rows_valid - 1) * a.ldo + cols_valid) * ES, 0x00020000);
       constexpr int WC = 32 * TN;            // slab row, floats
       constexpr int L4 = WC / 4;             // lanes per slab row
       constexpr int RPI = 64 / L4;           // rows per store instruction
       float* ws = reinterpret_cast<float*>(smem_raw + STG) + wave * (32 * WC);
       const int c4 = (lane % L4) * 4, rr = lane / L4;
       const int gcol = wn * WC + c4;                                   // column within the tile
-      const int lbase = gcol < cols_valid ? ((wm * (32 * TM) + rr) * a.ldo + gcol) * 4 : OOB;
+      const int lbase = gcol < cols_valid ? ((wm * (32 * TM) + rr) * a.ldo + gcol) * ES : OOB;
       __syncthreads();                       // every wave is done reading stage 1
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -852,12 +855,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             v[e] = (v[e] * a.w_inv + bv[e]) * a.out_scale;   // same expression as epilogue_rows
             if (a.epilogue == VFML_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
           }
-          const int roff = (i * 32 + p * RPI) * a.ldo * 4;
+          const int roff = (i * 32 + p * RPI) * a.ldo * ES;
 #ifndef VFML_STORE_AUX
 #define VFML_STORE_AUX 2      // nt: the volume is streamed out once
 #endif
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, gcol < cols_valid ? lbase + roff : OOB, 0,
-                                                 VFML_STORE_AUX);
+          if constexpr (H16) {
+            const h16x2 p0 = {(_Float16)v[0], (_Float16)v[1]}, p1 = {(_Float16)v[2], (_Float16)v[3]};
+            const u32x2 hv = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+            __builtin_amdgcn_raw_buffer_store_b64(hv, ro, gcol < cols_valid ? lbase + roff : OOB, 0, VFML_STORE_AUX);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, gcol < cols_valid ? lbase + roff : OOB, 0,
+                                                   VFML_STORE_AUX);
+          }
         }
         if constexpr (PERSIST && TN == 2 && FASTK) if (a.out_t) {   // (the general-loader instantiation would spill)
           // The transposed copy, out_t[column][row]: the block goes through the same 8 KiB as [column][row]
@@ -888,9 +897,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             }
           }
           const int rows_t = cols_valid, cols_t = rows_valid;      // extent of the transposed tile
-          float* tbase_t = a.out_t + (int64_t)cur_n0 * a.ld_out_t + cur_m0;
+          char* tbase_t = reinterpret_cast<char*>(a.out_t) + ((int64_t)cur_n0 * a.ld_out_t + cur_m0) * ES;
           const __amdgpu_buffer_rsrc_t rt =
-              __builtin_amdgcn_make_buffer_rsrc(tbase_t, 0, ((rows_t - 1) * a.ld_out_t + cols_t) * 4, 0x00020000);
+              __builtin_amdgcn_make_buffer_rsrc(tbase_t, 0, ((rows_t - 1) * a.ld_out_t + cols_t) * ES, 0x00020000);
           const int g = lane >> 3, cl = lane & 7;
 #pragma unroll
           for (int pp = 0; pp < 8; ++pp) {
@@ -901,8 +910,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             const int q0 = wm * (32 * TM) + i * 32 + 4 * g;         // first of the four pixels (columns of out_t)
             const int trow = wn * WC + c;
             const bool ok = trow < rows_t && q0 < cols_t;           // M % 4 == 0 (host check): a quad is whole
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt,
-                                                   ok ? (trow * a.ld_out_t + q0) * 4 : OOB, 0, VFML_STORE_AUX);
+            if constexpr (H16) {
+              const h16x2 p0 = {(_Float16)v[0], (_Float16)v[1]}, p1 = {(_Float16)v[2], (_Float16)v[3]};
+              const u32x2 hv = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+              __builtin_amdgcn_raw_buffer_store_b64(hv, rt, ok ? (trow * a.ld_out_t + q0) * 2 : OOB, 0, VFML_STORE_AUX);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt,
+                                                     ok ? (trow * a.ld_out_t + q0) * 4 : OOB, 0, VFML_STORE_AUX);
+            }
           }
         }
       }
@@ -1175,7 +1190,7 @@ int launch_lw_k(SplitArgs& a, hipStream_t s) {
 
 #endif  // VFML_EXPERIMENT_LW
 
-template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false>
+template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false, bool H16 = false>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
   constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
   constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
@@ -1186,7 +1201,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   a.ntiles = (a.cout + TBN - 1) / TBN;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM, MF16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM, MF16, H16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1198,7 +1213,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.mtiles * a.ntiles;
   const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
   const int grid = (int)(PERSIST && total > slots ? slots : total);
-  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM, MF16>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM, MF16, H16>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
   return vfml_check_launch("vfml_conv2d_split");
 }
 
@@ -1210,6 +1225,14 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     // last bit (a volume stored transposed and the reverse problem computed directly differ in the last ulp, which the
     // 32x32x16 form never does: tests/test_gpu_kernels.py::test_wide_gemm_with_transposed_second_output), so the
     // sliding job's "volume + transposed volume from one pass" would stop being bit-identical to from-scratch fields.
+    if (a.out_h16) {      // VFML_FMT_F16 outputs (host: implies fastk)
+      if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true, 3, false, true>(a, s);
+      if (a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2, false, true>(a, s);
+      if (a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1, false, true>(a, s);
+      if (a.nm == 5) return launch_dma_k<2, 2, 2, 2, true, true, false, 5, false, true>(a, s);
+      a.nm = 3;
+      return launch_dma_k<2, 2, 2, 2, true, true, false, 3, false, true>(a, s);
+    }
     if (a.cswap) return launch_dma_k<2, 2, 2, 2, true, true, true>(a, s);     // (host: cswap implies fastk and nm == 3)
     if (a.fastk && a.nm == 2) return launch_dma_k<2, 2, 2, 2, true, true, false, 2>(a, s);  // (host: bhi implies fastk, nm <= 2)
     if (a.fastk && a.nm == 1) return launch_dma_k<2, 2, 2, 2, true, true, false, 1>(a, s);
@@ -1613,7 +1636,8 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   VFML_REQUIRE(k_order != VFML_KORDER_CBLOCK64 || ((d->flags & VFML_CONV_MFMA1) && d->c0 % 64 == 0 && (d->c0 + d->c1) % 64 == 0 && d->cout > 32),
                "vfml_conv2d_split: VFML_KORDER_CBLOCK64 is the weight order of VFML_CONV_MFMA1 calls over whole 64-channel blocks "
                "with more than 32 output channels");
-  VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) && (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16) &&
+  VFML_REQUIRE((in_fmt == VFML_FMT_F32 || in_fmt == VFML_FMT_S16) &&
+               (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16 || (out_fmt == VFML_FMT_F16 && in_fmt == VFML_FMT_S16)) &&
                (aux_fmt == VFML_FMT_F32 || aux_fmt == VFML_FMT_S16), "vfml_conv2d_split: bad format selector");
   const bool in16 = in_fmt == VFML_FMT_S16;
   if (in16)
@@ -1712,6 +1736,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
              (!d->addend || (vfml_aligned16(d->addend) && d->ld_addend % 4 == 0));
   VFML_REQUIRE(!d->addend || d->ld_addend >= d->cout, "vfml_conv2d_split: ld_addend=%d < cout", d->ld_addend);
   a.out16 = out_fmt == VFML_FMT_S16;
+  a.out_h16 = out_fmt == VFML_FMT_F16;
   a.aux16 = aux_fmt == VFML_FMT_S16;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const bool bigc = a.ctot >= BK;
@@ -1765,9 +1790,14 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         a.src1_delta = two ? (a.d1off - a.d0off) * 4 : 0;
       }
       static const int direct_min = getenv("VFML_DIRECT_MIN") ? atoi(getenv("VFML_DIRECT_MIN")) : 1024;
-      a.direct = (d->epilogue == VFML_EPI_NONE || d->epilogue == VFML_EPI_RELU) && !d->addend && out_fmt == VFML_FMT_F32 &&
-                 !d->stats_part && d->cout >= direct_min && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&
+      // (VFML_FMT_F16 outputs exist in this form only: any width)
+      a.direct = (d->epilogue == VFML_EPI_NONE || d->epilogue == VFML_EPI_RELU) && !d->addend &&
+                 (out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_F16) && !d->stats_part &&
+                 (d->cout >= direct_min || out_fmt == VFML_FMT_F16) && d->cout % 4 == 0 && d->ldo % 4 == 0 && vfml_aligned16(d->out) &&
                  (!d->bias || vfml_aligned16(d->bias));
+      VFML_REQUIRE(out_fmt != VFML_FMT_F16 || (a.direct && a.fastk),
+                   "vfml_conv2d_split: VFML_FMT_F16 outputs are written by the GEMM form only (1x1 over whole 32-channel blocks, no "
+                   "addend / activation beyond ReLU, cout %% 4 == 0, ldo %% 4 == 0, 16-byte aligned out)");
       if (d->flags & VFML_CONV_SWAP_CROSS) {
         VFML_REQUIRE(a.direct && a.fastk, "vfml_conv2d_split: VFML_CONV_SWAP_CROSS is implemented by the GEMM form only "
                                           "(1x1 over whole 32-channel blocks, plain f32 out, cout >= 1024, cout %% 4 == 0)");

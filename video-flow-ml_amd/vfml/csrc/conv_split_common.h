@@ -26,6 +26,7 @@ struct SplitArgs {
   int mtiles, ntiles;
   int vec_ok;  // out/aux/bias 16-byte aligned and ldo, ld_aux % 4 == 0 -> float4 epilogue
   int out16, aux16;   // output / aux operands in the split-row format (VFML_FMT_S16)
+  int out_h16;        // GEMM form: out / out_t hold one f16 per element (VFML_FMT_F16)
   // LDS-DMA kernel: both weight planes through one descriptor at wbase (byte offsets of the planes, extent)
   const char* wbase; int whi_off, wlo_off, bytesb;
   int korder;   // VFML_KORDER_*
@@ -71,6 +72,7 @@ constexpr int BK = 32;
 constexpr int KG = BK / 8;  // 16-byte units (8 halves) per row per K step
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // 16-byte load through a buffer descriptor: an offset beyond num_records returns zeros, which is how
 // padding taps, K tails and out-of-range rows/columns are filled (no branch, no select on the data).

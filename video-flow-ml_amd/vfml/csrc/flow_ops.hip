@@ -27,6 +27,7 @@ struct LookupArgs {
   const float* coords; int ld_coords;
   float* out; int ld_out;
   int out16;
+  int vol16;     // the pyramids hold one f16 per element (VFML_FMT_F16; fixed-radius kernels only)
 };
 
 // One wave per query.  Per level the window's (2r+1)^2 bilinear samples all share the same
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
 // index arithmetic becomes multiplications by constants instead of integer divisions (the generic kernel
 // spends more issue slots on `e / psz`, `idx / side`, `c / (win*win)` than on its loads), and a lane
 // produces four consecutive output channels, stored as one 16-byte run (f32) or two 8-byte runs (split rows).
-template <int R, bool OUT16>
+template <int R, bool OUT16, bool VOL16 = false>
 __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(const LookupArgs a) {
   constexpr int SIDE = 2 * R + 2, PSZ = SIDE * SIDE, WIN = 2 * R + 1, WW = WIN * WIN;
   __shared__ float patch[LOOKUP_WAVES][FIXED_LEVELS][PSZ];
@@ -123,11 +124,13 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
     const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
     const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
     const int total = a.levels * PSZ;
-    const float* lp[FIXED_LEVELS];
+    constexpr int ES = VOL16 ? 2 : 4;        // bytes per texel of the volume
+    const char* lp[FIXED_LEVELS];
     int lw[FIXED_LEVELS], lh[FIXED_LEVELS];
 #pragma unroll
     for (int l = 0; l < FIXED_LEVELS; ++l) {
-      lp[l] = l < a.levels ? (a.table ? a.table[map * a.levels + l] : a.pyr[map][l]) + (int64_t)qq * a.ld[l] : nullptr;
+      lp[l] = l < a.levels ? reinterpret_cast<const char*>(a.table ? a.table[map * a.levels + l] : a.pyr[map][l]) + (int64_t)qq * a.ld[l] * ES
+                           : nullptr;
       lw[l] = a.wl[l];
       lh[l] = a.hl[l];
     }
@@ -148,10 +151,13 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
         const int x0 = (int)fminf(fmaxf(floorf(x), -65536.f), 65536.f) - R;
         const int y0 = (int)fminf(fmaxf(floorf(y), -65536.f), 65536.f) - R;
         const int xx = x0 + px, yy = y0 + py;
-        const float* base = l == 0 ? lp[0] : (l == 1 ? lp[1] : (l == 2 ? lp[2] : lp[3]));
+        const char* base = l == 0 ? lp[0] : (l == 1 ? lp[1] : (l == 2 ? lp[2] : lp[3]));
         const int wl = l == 0 ? lw[0] : (l == 1 ? lw[1] : (l == 2 ? lw[2] : lw[3]));
         const int hl = l == 0 ? lh[0] : (l == 1 ? lh[1] : (l == 2 ? lh[2] : lh[3]));
-        if (xx >= 0 && xx < wl && yy >= 0 && yy < hl) val[it] = base[yy * wl + xx];
+        if (xx >= 0 && xx < wl && yy >= 0 && yy < hl) {
+          if constexpr (VOL16) val[it] = (float)reinterpret_cast<const _Float16*>(base)[yy * wl + xx];
+          else val[it] = reinterpret_cast<const float*>(base)[yy * wl + xx];
+        }
       }
     }
 #pragma unroll
@@ -361,30 +367,32 @@ extern "C" int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, v
 
 static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
                             const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                            int ld_coords, float* out, int ld_out, int out_fmt, void* stream);
+                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
 
 extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                 int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
-                                float* out, int ld_out, int out_fmt, void* stream) {
+                                float* out, int ld_out, int out_fmt, int vol_fmt, void* stream) {
   VFML_REQUIRE(pyr, "vfml_corr_lookup: null pointer");
   return corr_lookup_impl(pyr, nullptr, hl, wl, ld, levels, radius, nmaps, q_per_map, coords, ld_coords, out, ld_out, out_fmt,
-                          stream);
+                          vol_fmt, stream);
 }
 
 extern "C" int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                          int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                                         int ld_coords, float* out, int ld_out, int out_fmt, void* stream) {
+                                         int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream) {
   VFML_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7u) == 0, "vfml_corr_lookup_indirect: null / misaligned table");
   return corr_lookup_impl(nullptr, table, hl, wl, ld, levels, radius, nmaps, q_per_map, coords, ld_coords, out, ld_out,
-                          out_fmt, stream);
+                          out_fmt, vol_fmt, stream);
 }
 
 static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
                             const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                            int ld_coords, float* out, int ld_out, int out_fmt, void* stream) {
+                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream) {
   VFML_REQUIRE(nmaps >= 1 && nmaps <= MAX_MAPS && q_per_map > 0, "vfml_corr_lookup: nmaps=%d out of [1,%d] or empty maps", nmaps, MAX_MAPS);
   const int nq = nmaps * q_per_map;
   VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
+  VFML_REQUIRE(vol_fmt == VFML_FMT_F32 || (vol_fmt == VFML_FMT_F16 && (radius == 3 || radius == 4) && levels <= FIXED_LEVELS),
+               "vfml_corr_lookup: vol_fmt is VFML_FMT_F32, or VFML_FMT_F16 with radius 3 / 4 and at most %d levels", FIXED_LEVELS);
   VFML_REQUIRE(hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
   VFML_REQUIRE(levels >= 1 && levels <= MAX_LEVELS, "vfml_corr_lookup: levels=%d out of [1,%d]", levels, MAX_LEVELS);
   VFML_REQUIRE(radius >= 1 && radius <= MAX_RADIUS, "vfml_corr_lookup: radius=%d out of [1,%d]", radius, MAX_RADIUS);
@@ -396,6 +404,7 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
                  "vfml_corr_lookup: split-row output needs a 32-byte aligned out and ld_out %% 8 == 0");
   LookupArgs a;
   a.out16 = out_fmt == VFML_FMT_S16;
+  a.vol16 = vol_fmt == VFML_FMT_F16;
   a.table = table;
   for (int m = 0; m < MAX_MAPS; ++m)
     for (int l = 0; l < MAX_LEVELS; ++l) a.pyr[m][l] = nullptr;
@@ -413,7 +422,15 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
   const dim3 grid((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), block(64 * LOOKUP_WAVES);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int generic = getenv("VFML_LOOKUP_GENERIC") ? atoi(getenv("VFML_LOOKUP_GENERIC")) : 0;
-  if (radius == 4 && !generic && levels <= FIXED_LEVELS) {
+  if (a.vol16) {
+    if (radius == 4) {
+      if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, false, true>), grid, block, 0, st, a);
+    } else {
+      if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, true, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, false, true>), grid, block, 0, st, a);
+    }
+  } else if (radius == 4 && !generic && levels <= FIXED_LEVELS) {
     if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, false>), grid, block, 0, st, a);
   } else if (radius == 3 && !generic && levels <= FIXED_LEVELS) {

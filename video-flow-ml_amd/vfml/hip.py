@@ -18,7 +18,7 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hi
 
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
-FMT_F32, FMT_S16 = 0, 1     # activation storage formats (include/vfml.h)
+FMT_F32, FMT_S16, FMT_F16 = 0, 1, 2     # storage formats (include/vfml.h; FMT_F16: correlation volumes only)
 KORDER_TAP, KORDER_CBLOCK, KORDER_CBLOCK64 = 0, 1, 2   # K-axis order of split weight planes (include/vfml.h)
 CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1, CONV_MFMA2A, CONV_PER_TAP = 1, 2, 4, 8, 16   # vfml_conv_desc.flags
 
@@ -113,9 +113,9 @@ def lib():
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                   c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
+                                   c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_corr_lookup_indirect.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                            c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
+                                            c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
@@ -130,7 +130,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 20:
+    if L.vfml_abi_version() != 21:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -216,7 +216,7 @@ def profile_end():
 
 
 def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, plain_f32_out=False, fastk=False,
-                 cswap=False, nm=3, same=None, per_tap=False, stats=False):
+                 cswap=False, nm=3, same=None, per_tap=False, stats=False, h16=False):
     """Template instantiation vfml_conv2d[_split] dispatches to, spelled as rocprofv3 prints it (mirrors
     the dispatch at the end of csrc/conv_gemm_split.hip; the rare 64-wide choice of the register-staged
     split kernel for cout > 64 is not modelled)."""
@@ -229,9 +229,9 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         if plain_f32_out and cout >= 1024 and cout % 4 == 0:
             if not fastk:
                 nm = 3
-            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}, false>"   # persistent GEMM form
+            return f"conv_gemm_dma_kernel<2, 2, 2, 2, true, {fk}, {'true' if cswap else 'false'}, {nm}, false, {'true' if h16 else 'false'}>"   # persistent GEMM form
         if cout <= 32:
-            return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}, true>"
+            return f"conv_gemm_dma_kernel<1, 1, 4, 1, false, false, false, {nm}, true, false>"
         # the shared-stage kernel (csrc/conv_gemm_tapx.hip: vfml_detail::tapx_cfg and the dispatcher's condition):
         # `same` = (kh, kw) of a stride-1 "same" convolution, else None
         tapx_mode = int(os.environ.get("VFML_TAPX", "1"))
@@ -244,7 +244,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
         if tapx and 64 < cout <= 96 and fills:
             return f"conv_gemm_tapx_kernel<2, 3, 4, 1, {nm}>"
         if cout <= 64:
-            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, {nm}, true>"
+            return f"conv_gemm_dma_kernel<2, 1, 2, 2, false, {fk}, false, {nm}, true, false>"
         def cost(tbm, tbn, mf, eff):
             tiles = -(-m // tbm) * -(-cout // tbn)
             return (tiles / 512.0 if tiles > 512 else 1.0) * mf / eff
@@ -257,7 +257,7 @@ def conv_variant(cout, split=False, ctot=32, in16=False, m=0, order=KORDER_TAP, 
                 best, t = c, name
         if tapx and t in ("3, 2, 2, 2", "2, 3, 2, 2") and (nm == 5 or tapx_mode >= 2):
             return f"conv_gemm_tapx_kernel<{t}, {nm}>"
-        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, {nm}, true>"
+        return f"conv_gemm_dma_kernel<{t}, false, {fk}, false, {nm}, true, false>"
     bigc = "true" if (ctot >= 32 or in16) else "false"
     return f"conv_gemm_split_kernel<{tile}, {bigc}, {'true' if in16 else 'false'}, {nm}>"
 
@@ -350,7 +350,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     e0.record()
     launch()
     e1.record()
-    plain = (epilogue in (EPI_NONE, EPI_RELU) and addend is None and out_fmt == FMT_F32 and ldo % 4 == 0)
+    plain = (epilogue in (EPI_NONE, EPI_RELU) and addend is None and out_fmt in (FMT_F32, FMT_F16) and ldo % 4 == 0)
     ctot = c0 + c1
     pointwise = kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0
     fastk = (is_split and in_fmt == FMT_S16 and (weight.order in (KORDER_CBLOCK, KORDER_CBLOCK64) or (pointwise and ctot % 32 == 0))
@@ -363,8 +363,10 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     elif is_split and weight.lo is None:
         nm_eff = {3: 2, 2: 2, 4: 1, 1: 1}[nm_eff]            # a single weight plane has no lo half to use
     same = (kh, kw) if (stride == 1 and ho == h and wo == w and not pointwise) else None
-    _PROFILE.append((conv_variant(cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
-                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross, nm_eff, same, per_tap),
+    # (a VFML_FMT_F16 output is written by the GEMM form whatever its width)
+    _PROFILE.append((conv_variant(max(cout, 1024) if out_fmt == FMT_F16 else cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
+                                  weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross, nm_eff, same, per_tap,
+                                  h16=out_fmt == FMT_F16),
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)
@@ -462,7 +464,7 @@ def ptr_table_set(table, tensors):
 
 
 def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coords, out, out_off, ld_out,
-                out_fmt=FMT_F32, table=None, nmaps=None):
+                out_fmt=FMT_F32, table=None, nmaps=None, vol_fmt=FMT_F32):
     """pyrs: list (one entry per query map) of lists (one flat float32 device tensor per level, rows =
     that map's q_per_map queries).  Queries / coords / out rows are ordered map-major.
     table (with nmaps): instead of `pyrs`, an int64 device tensor holding the same pointers, map-major
@@ -473,7 +475,7 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
             _check(lib().vfml_corr_lookup_indirect(c_void_p(table.data_ptr()), (c_int32 * L)(*hl), (c_int32 * L)(*wl),
                                                    (c_int32 * L)(*ld), L, radius, nmaps, q_per_map,
                                                    _ptr(_dev(coords), coords_off), ld_coords, _ptr(_dev(out), out_off),
-                                                   ld_out, out_fmt, _stream()), "vfml_corr_lookup_indirect")
+                                                   ld_out, out_fmt, vol_fmt, _stream()), "vfml_corr_lookup_indirect")
     else:
         if pyrs and torch.is_tensor(pyrs[0]):
             pyrs = [pyrs]
@@ -483,7 +485,7 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
         def launch():
             _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
                                           nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
-                                          _ptr(_dev(out), out_off), ld_out, out_fmt, _stream()), "vfml_corr_lookup")
+                                          _ptr(_dev(out), out_off), ld_out, out_fmt, vol_fmt, _stream()), "vfml_corr_lookup")
     if _PROFILE_HBM is None:
         launch()
         return
@@ -493,7 +495,7 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
     e1.record()
     # algorithmic bytes: per query and level the (2r+2)^2 integer-grid patch in, (2r+1)^2 samples out
     q = nmaps * q_per_map
-    _PROFILE_HBM.append(("corr_lookup", q * L * ((2 * radius + 2) ** 2 + (2 * radius + 1) ** 2) * 4.0, e0, e1))
+    _PROFILE_HBM.append(("corr_lookup", q * L * ((2 * radius + 2) ** 2 * (2.0 if vol_fmt == FMT_F16 else 4.0) + (2 * radius + 1) ** 2 * 4.0), e0, e1))
 
 
 def coords_init(coords1, n, h, w):

@@ -194,12 +194,13 @@ class MOFNetHIP(_Holder):
         return p
 
     def _enc_split_rows(self):
-        """Encoder activations as split rows through the LDS-DMA convolution kernel (VFML_ENC_S16=1), or f32 rows split
-        while register-staged (the default).  Measured A/B on one box at 1080p (profiles/r02_encoder_paths.md): the
-        split-row path is 0.25 ms per field SLOWER - the 64-channel layers at half resolution are bound by re-reading
-        every input pixel once per filter tap (1.2 GB of operand traffic per convolution against 46 us of MFMA work), in
-        either kernel; what they need is operand reuse across taps, not another staging path."""
-        return bool(os.environ.get("VFML_ENC_S16"))
+        """Encoder activations as split rows through the LDS-DMA convolution kernels (the default; `instnorm_apply` writes
+        split rows, the norm statistics come from the convolution epilogues), or f32 rows split while register-staged
+        (VFML_ENC_S16=0).  Measured A/B on one box at 1080p: with the per-tap kernel the split-row path was 0.25 ms per
+        field SLOWER (profiles/r02_encoder_paths.md: the 64-channel layers at half resolution re-read every input pixel
+        once per filter tap); with one activation stage per filter row on 256 x 64 / 256 x 96 tiles (conv_gemm_tapx.hip)
+        and the fast epilogue it is 0.2 ms FASTER (26.27 / 26.26 vs 26.42 / 26.50 ms, profiles/r02_kernel_anatomy.md)."""
+        return os.environ.get("VFML_ENC_S16", "1") != "0"
 
     def _split(self):
         """Every arithmetic but 'f32' runs the split-f16 kernels on split-row activations; they differ in the
@@ -235,7 +236,11 @@ class MOFNetHIP(_Holder):
     def _plan_key(self):
         """The arithmetic as part of a cached frame's identity."""
         p = self._precision()
-        return (p, tuple(sorted((k, str(v)) for k, v in (getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
+        vol = getattr(self.cfg, "corr_volume", "f32")
+        if vol not in ("f32", "f16"):
+            raise ValueError(f"cfg.corr_volume must be 'f32' or 'f16', got {vol!r}")
+        key = (p, tuple(sorted((k, str(v)) for k, v in (getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
+        return key if vol == "f32" else (key, vol)
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, name, numel, device, dtype=torch.float32, zero=False):
@@ -547,6 +552,12 @@ class MOFNetHIP(_Holder):
                 wl.append(wl[-1] // 2)
             Sl = [hl[l] * wl[l] for l in range(L)]
             ldl = [(s + 31) // 32 * 32 for s in Sl]
+            # cfg.corr_volume 'f16': the pyramids as one f16 per value, written by the GEMM form (which needs every level's
+            # width a multiple of 4 and split-row query features) - other geometries keep f32 volumes
+            vol16 = (getattr(cfg, "corr_volume", "f32") == "f16" and AF == hip.FMT_S16 and Pn % 4 == 0
+                     and all(s % 4 == 0 for s in Sl))
+            VF = hip.FMT_F16 if vol16 else hip.FMT_F32
+            psz = [(Pn * ldl[l] + 1) // 2 if vol16 else Pn * ldl[l] for l in range(L)]     # floats per level buffer
             keys = None
             if frame_keys is not None:   # geometry and arithmetic are part of a cached frame's identity
                 keys = [(k, H, W, L, self._plan_key(), self._packed_serial) for k in frame_keys]
@@ -568,12 +579,12 @@ class MOFNetHIP(_Holder):
                     pyr = self._cache_get("p", pk) if pk is not None else None
                     if pyr is None:
                         if pk is None:    # uncached call: reuse one workspace set per problem slot
-                            pyr = [self._buf(f"pyr_{d}{c}_{l}", Pn * ldl[l], dev) for l in range(L)]
+                            pyr = [self._buf(f"pyr_{d}{c}_{l}", psz[l], dev) for l in range(L)]
                         else:
                             # (registered before it is filled: same stream, and the next allocation then sees
                             # the right count and retires a stale pyramid instead of asking the allocator)
                             lim = 2 * (N - 2) + 2
-                            pyr = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=lim)
+                            pyr = self._pyramid_buffers(psz, dev, limit=lim)
                             self._cache_put("p", pk, pyr, limit=lim)
                         # Level 0 of the reverse problem (tgt -> c) is the transpose of this one's: when it is
                         # going to be needed (tgt is, or next field becomes, a centre frame: the "f" problems of
@@ -588,23 +599,20 @@ class MOFNetHIP(_Holder):
                                 and not os.environ.get("VFML_NO_DUAL"))      # (A/B switch; results are identical)
                         rev = None
                         if dual:
-                            rev = self._pyramid_buffers([Pn * ldl[l] for l in range(L)], dev, limit=lim)
+                            rev = self._pyramid_buffers(psz, dev, limit=lim)
                             self._cache_put("p", rk, rev, limit=lim)
                         cnm = self._nm("corr") if self._split() else 3
                         for l in range(L):
                             # (one MFMA per product is symmetric in its operands: no swapped cross terms to order)
                             hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[l],
-                                       ldl[l], out_scale=scale, in_fmt=AF,
+                                       ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF,
                                        swap_cross=(d == "b" and l == 0 and gemm_form and cnm == 3),
                                        out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0,
                                        mfma=cnm)
                         if dual:
                             for l in range(1, L):
                                 hip.conv2d(feats[tgt][0], D, D, 1, 1, Pn, feats[c][1][l], None, Sl[l], 1, 1, rev[l],
-                                           ldl[l], out_scale=scale, in_fmt=AF, mfma=cnm)
-                        if os.environ.get("VFML_EXPERIMENT_CORR16"):   # precision experiment: the volume rounded to f16
-                            for t in pyr + (rev or []):
-                                t.copy_(t.half().float())
+                                           ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF, mfma=cnm)
                     pyrs[d].append(pyr)
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
@@ -662,9 +670,9 @@ class MOFNetHIP(_Holder):
                     nm = min(M, left + 2) if pick_only and not self.tri_frame else M
                     # K5
                     hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF,
-                                    table=tab_f, nmaps=nm)
+                                    table=tab_f, nmaps=nm, vol_fmt=VF)
                     hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF,
-                                    table=tab_b, nmaps=nm)
+                                    table=tab_b, nmaps=nm, vol_fmt=VF)
                     # motion encoder
                     wgt, b = P[f"{ub}.encoder.convc1"]
                     hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
@@ -739,7 +747,7 @@ class MOFNetHIP(_Holder):
                             hip.convex_upsample(coords1, c * Pn * 4, 2 * d, mask, c * Pn * 1152 + d * 576, 1152, h, w,
                                                 up_fixed, out_off=(d * M + c) * H * W * 2)
 
-            gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(),
+            gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(), vol16,
                     self._packed_serial, str(dev))
             self._run_body(body, gkey, dev)
             up = up_fixed.clone().view(nflows, H, W, 2)          # the caller owns its field; the fixed buffer is reused
