@@ -90,6 +90,14 @@ typedef struct vfml_conv_desc {
                                                        32 with split-row sources - VFML_STATS_ROWS_*): the first
                                                        pass of vfml_instnorm_stats done where the tile still is
                                                        in LDS; fold with vfml_instnorm_finalize               */
+  float* ksplit_ws;                                 /* optional (vfml_conv2d_split, GEMM form, plain f32 out): a workspace
+                                                       shaped like out ([n*h*w][ldo] floats), followed - when out_t is
+                                                       given - by one shaped like out_t ([cout][ld_out_t]).  A GEMM with
+                                                       few output tiles and a long K axis (the MemFlow read-out: 254
+                                                       tiles on 512 resident slots, K = 32 400) is then run as two work
+                                                       items per tile, one per half of K: the second half's sums go to
+                                                       the workspace and are added to out / out_t (first + second, a
+                                                       fixed order) by passes the call launches itself */
 } vfml_conv_desc;
 
 /* flags: accumulate the two cross terms of the split product in the order (a_lo*b_hi, a_hi*b_lo) instead of

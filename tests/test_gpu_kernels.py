@@ -1023,3 +1023,38 @@ def test_corr_lookup_reads_f16_volumes(gpu, radius, levels):
         assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match="vol_fmt"):
         hip.corr_lookup([_as_f32_storage(v) for v in vol16], hl, wl, ld, 2, P, coords, 0, 4, a, 0, ldo, vol_fmt=hip.FMT_F16)
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_gemm_form_split_k(gpu, dual):
+    """vfml_conv_desc.ksplit_ws: a GEMM with few tiles and a long K axis runs as two work items per tile (one per half of
+    K, the second half's sums added by a pass of the call): same result as the one-pass call up to the order of one f32
+    addition per element, pad columns untouched, with and without the transposed second output; K not a multiple of the
+    half (the second half reads past K: zeros)."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(3)
+    P, S, D = 128, 2000, 4160 + 32          # 1 x 16 tiles of 128 x 128, 131 steps of 32 channels (odd)
+    f1, f2 = torch.randn(P, D, generator=g) / 8, torch.randn(S, D, generator=g) / 8
+    ld, ldt = (S + 31) // 32 * 32, P
+
+    def rows(f):
+        t = torch.empty(f.numel(), device=gpu)
+        hip.to_s16(f.cuda().reshape(-1), f.shape[0], D, D, t, D)
+        return t
+
+    w = hip.SplitWeight(S, D, torch.device("cuda")).fill(f2.cuda().reshape(-1).contiguous(), scale=16.0)
+    ref = (f1.double() @ f2.double().t()).float()
+    outs = []
+    for ws in (None, torch.full((P * ld + S * ldt,), float("nan"), device=gpu)):
+        out = torch.full((P * ld,), 7.0, device=gpu)
+        out_t = torch.full((S * ldt,), 9.0, device=gpu) if dual else None
+        hip.conv2d(rows(f1), D, D, 1, 1, P, w, None, S, 1, 1, out, ld, in_fmt=hip.FMT_S16, out_t=out_t,
+                   ld_out_t=ldt if dual else 0, ksplit_ws=ws)
+        got = out.view(P, ld).cpu()
+        assert rel_err(got[:, :S], ref) < CONV_TOL["f16x3"]
+        assert (got[:, S:] == 7.0).all()
+        if dual:
+            assert torch.equal(out_t.view(S, ldt).cpu(), got[:, :S].t())
+        outs.append(got)
+    assert not torch.equal(outs[0], outs[1])            # (the split call did take the other route)
+    assert rel_err(outs[0][:, :S], outs[1][:, :S]) < 5e-6

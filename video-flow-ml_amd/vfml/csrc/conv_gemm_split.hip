@@ -391,7 +391,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   float* sC = reinterpret_cast<float*>(smem_raw);
 
   // this workgroup's tiles (XCD x = blockIdx & 7 owns a contiguous share of the tile space)
-  const int total = a.mtiles * a.ntiles;
+  // (a.ksplit == 2, persistent GEMM form: every tile is two work items, one per half of the K axis)
+  const int total = a.mtiles * a.ntiles * (PERSIST ? a.ksplit : 1);
   int tile, tile_end, tile_step;
   {
     const int G = gridDim.x, xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   int kc, kky, kkx;   // channel within the tap and tap position of k = k0 + 8*kg, advanced by BK per step
   int scb = 0, sky = 0, skx = 0;   // uniform-step loader: channel block and tap of the step (scalars)
   int m0, n0;
+  int ks = 0;          // a.ksplit == 2: the half of the K axis this work item covers
 #ifdef VFML_EXPERIMENT_ZERODESC   // timing only: every DMA is range-checked away, the instruction stream stays
   __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, 0, 0x00020000);
 #else
@@ -426,8 +428,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #endif
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
 
+  // steps per work item (rounded up to even; a second half that reaches past K reads zeros on the source side)
+  const int nk = PERSIST && a.ksplit == 2 ? (((a.Kp / KSTEP + 1) >> 1) + 1) & ~1 : (a.Kp / KSTEP + 1) & ~1;
   auto setup = [&](int tl) {
     int nt, mt;
+    if (PERSIST && a.ksplit == 2) {
+      ks = tl & 1;
+      tl >>= 1;
+    }
     if (a.ntiles >= 8) {
       // wide outputs (GEMMs): the 64 tiles an XCD has in flight form an 8 x 8 block, so every operand
       // tile it pulls into its L2 serves 8 workgroups (n-fastest order streams the whole second operand
@@ -489,7 +497,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
         tapok[j] = ~tapok[j];
         if (AHI && !H64 && hl) rp0[j] |= (int)0x80000000;      // lo slots of the activations: never fetched
       }
-      scb = sky = skx = 0;
+      scb = ks * nk * KSTEP;         // (ksplit: pointwise calls only - the K axis is the channel axis)
+      sky = skx = 0;
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   int va[AP];
   int soffA = 0, soffB = 0;      // scalar offsets of the step (buffer soffset operand)
   auto prep_step = [&](int k0) {
-    soffB = k0 * (H64 ? 4 : 2);          // k0 counts steps x 32: a 64-channel step is 128 bytes of the hi plane
+    soffB = (k0 + ks * nk * BK) * (H64 ? 4 : 2);   // k0 counts steps x 32: a 64-channel step is 128 bytes of the hi plane
     if constexpr (FASTK) {
       // every lane of the step reads the same tap of the same 32-channel block: the tap / channel / source
       // offset is one scalar, the per-piece work is "row valid for this tap?" -> two VALU instructions
@@ -723,7 +732,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 
   // The step count is rounded up to even (one all-zero step when odd: out of range on the source side,
   // the weight side reads the next row's first step - multiplied by zeros).
-  const int nk = (a.Kp / KSTEP + 1) & ~1;
   constexpr int NSTORE = TM * TN * 4;                    // direct epilogue: 16-byte stores per thread, all issued
   constexpr int RELAXED = NSTORE < 63 ? NSTORE : 63;     // vmcnt that still covers the older DMAs
   constexpr int NSTORE_T = NSTORE + TM * TN * 4;         // with the transposed second output
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
-    const int cur_m0 = m0, cur_n0 = n0;
+    const int cur_m0 = m0, cur_n0 = n0, cur_ks = ks;
     const int next = PERSIST ? tile + tile_step : tile_end;
     // (direct epilogue) this tile's bias quad, loaded before the K loop: a load in the epilogue would make its
     // s_waitcnt drain the previous tile's stores as well
@@ -814,7 +822,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       const int cols_valid = a.cout - cur_n0 < TBN ? a.cout - cur_n0 : TBN;
       // (out_h16: VFML_FMT_F16 outputs - one f16 per element, 8-byte stores of four; same store count, half the bytes)
       constexpr int ES = H16 ? 2 : 4;
-      char* tbase = reinterpret_cast<char*>(a.out) + ((int64_t)cur_m0 * a.ldo + cur_n0) * ES;
+      // (ksplit: the second half's partial sums go to the workspace; the host adds them after the launch)
+      char* tbase = reinterpret_cast<char*>(cur_ks ? a.out_k1 : a.out) + ((int64_t)cur_m0 * a.ldo + cur_n0) * ES;
       const __amdgpu_buffer_rsrc_t ro =
           __builtin_amdgcn_make_buffer_rsrc(tbase, 0, ((rows_valid - 1) * a.ldo + cols_valid) * ES, 0x00020000);
       constexpr int WC = 32 * TN;            // slab row, floats
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             }
           }
           const int rows_t = cols_valid, cols_t = rows_valid;      // extent of the transposed tile
-          char* tbase_t = reinterpret_cast<char*>(a.out_t) + ((int64_t)cur_n0 * a.ld_out_t + cur_m0) * ES;
+          char* tbase_t = reinterpret_cast<char*>(cur_ks ? a.out_t_k1 : a.out_t) + ((int64_t)cur_n0 * a.ld_out_t + cur_m0) * ES;
           const __amdgpu_buffer_rsrc_t rt =
               __builtin_amdgcn_make_buffer_rsrc(tbase_t, 0, ((rows_t - 1) * a.ld_out_t + cols_t) * ES, 0x00020000);
           const int g = lane >> 3, cl = lane & 7;
@@ -1210,7 +1219,7 @@ int launch_dma_k(SplitArgs& a, hipStream_t s) {
     attr_done = true;
   }
   // PERSIST: one workgroup per resident slot (256 CUs x 2 or 1), fewer when there are fewer tiles
-  const int64_t total = (int64_t)a.mtiles * a.ntiles;
+  const int64_t total = (int64_t)a.mtiles * a.ntiles * (PERSIST ? a.ksplit : 1);     // work items
   const int64_t slots = 256 * (WM * WN == 4 ? 2 : 1);
   const int grid = (int)(PERSIST && total > slots ? slots : total);
   hipLaunchKernelGGL((conv_gemm_dma_kernel<TM, TN, WM, WN, PERSIST, FASTK, CSWAP, NM, MF16, H16>), dim3(grid), dim3(WM * WN * 64), lds, s, a);
@@ -1611,6 +1620,17 @@ extern "C" int vfml_split_f16(const float* src, int64_t rows, int k, int ld, flo
   return vfml_check_launch("vfml_split_f16");
 }
 
+// out[r][0 .. 4 q4) += add[r][0 .. 4 q4): the second half of a split K axis (vfml_conv_desc.ksplit_ws)
+__global__ void add_rows_kernel(float* __restrict__ out, const float* __restrict__ add, int rows, int q4, int ld) {
+  const int64_t total = (int64_t)rows * q4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q4;
+    const int64_t o = r * ld + (i - r * q4) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(out + o), y = *reinterpret_cast<const f32x4*>(add + o);
+    *reinterpret_cast<f32x4*>(out + o) = x + y;
+  }
+}
+
 extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, const void* w_lo, int kp, float w_scale,
                                  int in_fmt, int out_fmt, int aux_fmt, int k_order, void* stream) {
   VFML_REQUIRE(d != nullptr, "vfml_conv2d_split: null descriptor");
@@ -1703,6 +1723,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   SplitArgs a;
   a.wbase = nullptr; a.whi_off = a.wlo_off = a.bytesb = 0; a.korder = k_order; a.direct = 0; a.fastk = 0; a.abias = 0; a.src1_delta = 0; a.out_t = nullptr; a.ld_out_t = 0; a.cswap = 0; a.bhi = 0;
   a.stats_part = d->stats_part;
+  a.ksplit = 1; a.out_k1 = nullptr; a.out_t_k1 = nullptr;
   static const int fast_epi = getenv("VFML_FAST_EPI") ? atoi(getenv("VFML_FAST_EPI")) : 1;
   a.fast_epi = fast_epi;
   a.nm = (d->flags & VFML_CONV_MFMA1) ? 1 : (d->flags & VFML_CONV_MFMA2A) ? (bhi ? 1 : 4) : ((d->flags & VFML_CONV_MFMA2) || bhi) ? 2 : 3;
@@ -1813,6 +1834,22 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
                      "epilogue, pixels %% 4 == 0, ld_out_t %% 4 == 0 and >= pixels, 16-byte alignment");
         a.out_t = d->out_t; a.ld_out_t = d->ld_out_t;
       }
+      // A GEMM with few tiles and a long K axis (the MemFlow read-out: 254 tiles of 128 x 128 on 512 resident slots, one
+      // workgroup per CU streaming 8 MB of its operand): two work items per tile, one per half of K, when the caller gave
+      // a workspace for the second half's sums
+      bool ksplit = false;
+      if (d->ksplit_ws) {
+        VFML_REQUIRE(vfml_aligned16(d->ksplit_ws), "vfml_conv2d_split: ksplit_ws must be 16-byte aligned");
+        static const int no_ksplit = getenv("VFML_NO_KSPLIT") ? atoi(getenv("VFML_NO_KSPLIT")) : 0;
+        const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((d->cout + 127) / 128);
+        ksplit = !no_ksplit && a.direct && a.fastk && a.pointwise && out_fmt == VFML_FMT_F32 && !a.cswap && tiles <= 256 &&
+                 kp >= 4096;
+        if (ksplit) {     // (the workspace holds the primary output's shape, then - with out_t - the transposed one's)
+          a.ksplit = 2;
+          a.out_k1 = d->ksplit_ws;
+          a.out_t_k1 = d->ksplit_ws + (int64_t)a.M * d->ldo;
+        }
+      }
       const char* tile_env = getenv("VFML_DMA_TILE");   // experiments / tests: "TM,TN,WM,WN" (read per call)
       int cfg = d->cout > 32 ? 2122 : 1141;
       if (d->cout > 64) {
@@ -1848,6 +1885,18 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         // (VFML_TAPX=2: also the three-MFMA calls on the 192 x 128 / 128 x 192 tiles, where the two kernels run level)
         const int tcfg = vfml_detail::tapx_cfg(a, cfg, forced);
         if (tcfg && (tapx >= 2 || forced || a.nm == 5 || tcfg == 2241 || tcfg == 2341)) return vfml_detail::launch_tapx(a, tcfg, s);
+      }
+      if (a.ksplit == 2) {
+        // (the GEMM form is one tile shape; the partial sums of the second half of K are added once the launch is queued)
+        const int rc = launch_dma<2, 2, 2, 2>(a, s);
+        if (rc) return rc;
+        const int64_t quads = (int64_t)a.M * (d->cout / 4);
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((quads + 255) / 256 < 65535 * 16 ? (quads + 255) / 256 : 65535 * 16)), dim3(256), 0, s,
+                           d->out, d->ksplit_ws, a.M, d->cout / 4, d->ldo);
+        if (d->out_t)      // [cout][ld_out_t] with M valid columns (M % 4 == 0: host check of out_t)
+          hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((quads + 255) / 256 < 65535 * 16 ? (quads + 255) / 256 : 65535 * 16)), dim3(256), 0, s,
+                             d->out_t, a.out_t_k1, d->cout, a.M / 4, d->ld_out_t);
+        return vfml_check_launch("vfml_conv2d_split");
       }
       switch (cfg) {
         case 3222: return launch_dma<3, 2, 2, 2>(a, s);   // 192 x 128, 2 workgroups per CU

@@ -42,6 +42,7 @@ struct SplitArgs {
   double* stats_part;           // register-staged kernel: per row tile and channel {sum, sum of squares} of the result
   int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
   int fast_epi;                 // 0: the general epilogue routine everywhere (VFML_FAST_EPI=0, A/B)
+  int ksplit; float* out_k1; float* out_t_k1;   // persistent GEMM form: 2 = two work items per tile, one per half of K; the second half's sums go to out_k1 (out_t_k1)
 };
 // conv_gemm_tapx.hip: the kernel that shares one activation stage between the taps of a filter row
 #define VFML_TAPX_KWMAX 5      // widest filter row it is built for

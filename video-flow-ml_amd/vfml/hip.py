@@ -40,6 +40,7 @@ class ConvDesc(ctypes.Structure):
         ("out_t", c_void_p), ("ld_out_t", c_int32),
         ("flags", c_int32),
         ("stats_part", c_void_p),
+        ("ksplit_ws", c_void_p),
     ]
 
 
@@ -303,7 +304,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
-           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3, per_tap=False):
+           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3, per_tap=False, ksplit_ws=None):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers).  mfma: terms of the split-f16 product (3; 2 or "2w" = weights as plain
     f16; "2a" = activations as plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA2A / _MFMA1).  per_tap:
@@ -328,6 +329,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
         raise ValueError(f"mfma={mfma!r}: 1, 2 ('2w'), '2a' or 3 (3 with swap_cross)")
     d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, "2a": CONV_MFMA2A, 1: CONV_MFMA1}[mfma] | (CONV_PER_TAP if per_tap else 0)
     d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
+    d.ksplit_ws = _ptr(_dev(ksplit_ws)) if ksplit_ws is not None else None      # GEMM form: second half of K (vfml.h)
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
         def launch():

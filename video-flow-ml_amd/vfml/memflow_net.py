@@ -270,6 +270,7 @@ class MemFlowNetHIP(MOFNetHIP):
                 vrows = self._buf("att_vt", AD * ldA, dev)            # V^T as split rows [AD][ldA]
                 ro = self._buf("att_ro", AD * ldA, dev)               # the GEMM's primary output [AD][ldA] (unused)
                 ro_t = self._buf("att_ro_t", Pn * AD, dev)            # its transpose: attn . v, [Pn][AD]
+                ro_ws = self._buf("att_ro_ws", AD * ldA + Pn * AD, dev)   # second half of the K axis (vfml.h ksplit_ws)
             else:
                 vt = hip.SplitWeight(AD, P8, dev)
 
@@ -300,7 +301,7 @@ class MemFlowNetHIP(MOFNetHIP):
                 for k in range(B if plain else 0):
                     hip.transpose_to_s16(val, Pn, AD, AD, vrows, ldA, scale=16.0, src_off=k * Pn * AD)
                     hip.conv2d(vrows, ldA, ldA, AD, 1, 1, attn[k], None, Pn, 1, 1, ro, ldA, out_scale=1.0 / 16.0,
-                               in_fmt=AF, out_t=ro_t, ld_out_t=AD, mfma=1 if v_f16 else 3)
+                               in_fmt=AF, out_t=ro_t, ld_out_t=AD, mfma=1 if v_f16 else 3, ksplit_ws=ro_ws)
                     hip.add_to_s16(ro_t, AD, G, GLD, G, GLD, Pn, AD, scale=gamma, aux_off=k * Pn * GLD + MF,
                                    out_off=k * Pn * GLD + MT)
                 for k in range(0 if plain else B):
