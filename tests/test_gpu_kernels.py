@@ -1058,3 +1058,24 @@ def test_gemm_form_split_k(gpu, dual):
         outs.append(got)
     assert not torch.equal(outs[0], outs[1])            # (the split call did take the other route)
     assert rel_err(outs[0][:, :S], outs[1][:, :S]) < 5e-6
+
+
+@pytest.mark.parametrize("n,chunks,c", [(2, 3000, 64), (1, 16200, 96), (1, 1023, 64), (1, 2048, 12)])
+def test_instnorm_finalize_many_partials(gpu, n, chunks, c):
+    """vfml_instnorm_finalize over thousands of partials per channel (the split-row convolutions leave one per 32 pixels):
+    the slice-wise first pass (c % 8 == 0, >= 1024 chunks) and the direct kernel agree with float64 sums; repeatable."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(chunks)
+    hw = chunks * 32
+    x = torch.rand(n, chunks, c, 32, generator=g, dtype=torch.float64) * 2 - 0.5
+    part = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).contiguous().cuda()          # [n][chunks][c][2] doubles
+    mean = x.permute(0, 2, 1, 3).reshape(n, c, -1).mean(-1)
+    var = x.permute(0, 2, 1, 3).reshape(n, c, -1).var(-1, unbiased=False)
+    want = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], -1).float()
+    st = torch.empty(n * c * 2, device=gpu)
+    hip.instnorm_finalize(part, n, chunks, c, hw, st)
+    got = st.view(n, c, 2).cpu()
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-7)
+    st2 = torch.empty_like(st)
+    hip.instnorm_finalize(part, n, chunks, c, hw, st2)
+    assert torch.equal(st, st2)

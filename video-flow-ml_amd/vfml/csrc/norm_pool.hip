@@ -1,5 +1,6 @@
 // HBM-bound helper passes: input normalisation (K1), instance-norm statistics / apply (K2),
 // 2x2 average pooling of feature maps (K4 feeder).  All are streaming float4 kernels.
+#include <stdlib.h>
 #include "vfml_common.h"
 
 namespace {
@@ -127,6 +128,42 @@ __global__ __launch_bounds__(FINAL_THREADS) void instnorm_final_kernel(const dou
     if (var < 0) var = 0;
     stats[2 * i + 0] = (float)mean;
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// With many partials per channel (the split-row convolutions leave one per 32 pixels: 16 200 at 540 x 960) the kernel above
+// reads 16 bytes per thread at a stride of c * 16 bytes - every 128-byte line eight times, by eight workgroups (23 us per
+// call, 30 calls per field).  First pass for that case: one workgroup per (n, 8 channels, slice of the chunks), a thread per
+// (channel, lane): eight threads read one 128-byte line, a slice's 32 lane sums are folded in lane order -> [n][slices][c][2]
+// partials that the kernel above finishes.  Fixed association: bitwise reproducible.
+constexpr int FOLD_SLICES = 64;
+__global__ __launch_bounds__(256) void instnorm_fold_kernel(const double* __restrict__ part, int chunks, int c,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[32][8][2];
+  const int cgs = c / 8;
+  const int sl = blockIdx.x % FOLD_SLICES, cg = (blockIdx.x / FOLD_SLICES) % cgs, nn = blockIdx.x / (FOLD_SLICES * cgs);
+  const int ch = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int per = (chunks + FOLD_SLICES - 1) / FOLD_SLICES;
+  const int k0 = sl * per, k1 = k0 + per < chunks ? k0 + per : chunks;
+  const double* base = part + ((int64_t)nn * chunks * c + cg * 8 + ch) * 2;
+  double s0 = 0, q0 = 0;
+  for (int k = k0 + lane; k < k1; k += 32) {
+    const double* p = base + (int64_t)k * c * 2;
+    s0 += p[0];
+    q0 += p[1];
+  }
+  sh[lane][ch][0] = s0;
+  sh[lane][ch][1] = q0;
+  __syncthreads();
+  if (lane == 0) {
+    double ss = 0, qq = 0;
+    for (int l = 0; l < 32; ++l) {
+      ss += sh[l][ch][0];
+      qq += sh[l][ch][1];
+    }
+    double* o = out + (((int64_t)nn * FOLD_SLICES + sl) * c + cg * 8 + ch) * 2;
+    o[0] = ss;
+    o[1] = qq;
   }
 }
 
@@ -262,7 +299,26 @@ extern "C" int vfml_instnorm_stats(const float* x, int n, int hw, int c, float e
 extern "C" int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats,
                                       void* stream) {
   VFML_REQUIRE(part && stats && n > 0 && chunks > 0 && c > 0 && hw > 0, "vfml_instnorm_finalize: bad argument");
-  hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, reinterpret_cast<hipStream_t>(stream), part, n, chunks,
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // many partials: fold them slice-wise with coalesced reads first (scratch: 1 MiB per device, allocated on first use -
+  // the encoders run outside any stream capture; calls on one stream, as the engine makes them, are ordered)
+  constexpr int64_t SCRATCH = 1 << 20;
+  static const int no_fold = getenv("VFML_NO_NORM_FOLD") ? atoi(getenv("VFML_NO_NORM_FOLD")) : 0;     // (A/B)
+  if (!no_fold && chunks >= 1024 && c % 8 == 0 && (int64_t)n * FOLD_SLICES * c * 16 <= SCRATCH) {
+    static double* scratch[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (!scratch[dev] && hipMalloc(&scratch[dev], SCRATCH) != hipSuccess) scratch[dev] = nullptr;
+      if (scratch[dev]) {
+        hipLaunchKernelGGL(instnorm_fold_kernel, dim3(n * (c / 8) * FOLD_SLICES), dim3(256), 0, st, part, chunks, c, scratch[dev]);
+        hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, st, (const double*)scratch[dev], n, FOLD_SLICES,
+                           c, hw, eps, stats);
+        return vfml_check_launch("vfml_instnorm_finalize");
+      }
+    }
+    (void)hipGetLastError();
+  }
+  hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, st, part, n, chunks,
                      c, hw, eps, stats);
   return vfml_check_launch("vfml_instnorm_finalize");
 }
