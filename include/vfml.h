@@ -246,6 +246,13 @@ int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, cons
                               float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
 int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream);
 
+/* The 7x7 convolution over the 4-channel flow map (motion encoder, convf1) as a 7x1 convolution over 32 channels: this pass
+ * writes, per pixel, the seven horizontal taps' flow quads (zeros outside the image row) as one split-row block of 32
+ * channels - channel kx*4 + c = flow[y][x + kx - 3][c], channels 28..31 zero - 12 MB at 1080p/8; the vertical taps are then
+ * the LDS-DMA convolution kernel's own (kh = 7, kw = 1, weights repacked to [cout][ky][kx*4 + c]).  flow: [n*h*w][4] f32,
+ * rows: [n*h*w][32] split rows (VFML_FMT_S16, 32-byte aligned). */
+int vfml_flow_rows7(const float* flow, int n, int h, int w, float* rows, void* stream);
+
 /* A 3x3 "same" convolution with FOUR output channels as a 1x1 convolution to 36 (tap-major: column (ky*3+kx)*4 + o holds
  * sum_c w[o][c][ky][kx] x[.][c]) followed by this pass: out[p][o] = bias[o] + sum over the nine taps inside the image of
  * t[p + (ky-1) w + (kx-1)][(ky*3+kx)*4 + o], taps in ky-major order.  The update block's flow head (256 -> 4) costs nine

@@ -1079,3 +1079,28 @@ def test_instnorm_finalize_many_partials(gpu, n, chunks, c):
     st2 = torch.empty_like(st)
     hip.instnorm_finalize(part, n, chunks, c, hw, st2)
     assert torch.equal(st, st2)
+
+
+def test_flow_rows7_turns_the_7x7_flow_convolution_into_7x1(gpu):
+    """vfml_flow_rows7 + a 7x1 convolution over its 32 channels == the 7x7 'same' convolution over the 4-channel flow map."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(12)
+    n, H, W, cout = 2, 11, 17, 128
+    x = torch.randn(n, 4, H, W, generator=g) * 3
+    wt = torch.randn(cout, 4, 7, 7, generator=g) / 14
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=3)).float()
+    P = n * H * W
+    rows = torch.full((P * 32,), float("nan"), device=gpu)
+    hip.flow_rows7(nhwc(x), n, H, W, rows)
+    back = torch.empty(P * 32, device=gpu)                      # split rows -> f32 through a 1x1 identity is overkill: check
+    w7 = torch.zeros(cout, 32, 7, 1)                            # the rows through the convolution itself
+    w7[:, :28, :, 0] = wt.permute(0, 3, 1, 2).reshape(cout, 28, 7)
+    w = as_weight(pack_conv_weight(w7, cblock=True), cout, "f16x3", order=hip.KORDER_CBLOCK)
+    out = torch.full((P * cout,), float("nan"), device=gpu)
+    hip.conv2d(rows, 32, 32, n, H, W, w, b.cuda(), cout, 7, 1, out, cout, pad_h=3, epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16)
+    got = from_nhwc(out, n, H, W, cout)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < CONV_TOL["f16x3"], rel_err(got, ref)
+    del back

@@ -228,6 +228,33 @@ __global__ void coords_init_kernel(f32x4* __restrict__ coords, int h, int w, int
   }
 }
 
+// rows[p] = the seven horizontal taps' flow quads of pixel p as 32 split-row channels (include/vfml.h vfml_flow_rows7):
+// one thread per (pixel, 8-channel unit) = two taps
+__global__ void flow_rows7_kernel(const f32x4* __restrict__ flow, int w, int64_t total, char* __restrict__ rows) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total * 4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i >> 2;
+    const int u = (int)(i & 3);
+    const int x = (int)(p % w);
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+    const int x0 = x + 2 * u - 3, x1 = x0 + 1;
+    if (x0 >= 0 && x0 < w) t0 = flow[p + 2 * u - 3];
+    if (u < 3 && x1 >= 0 && x1 < w) t1 = flow[p + 2 * u - 2];        // (unit 3's second quad = channels 28..31: zero)
+    vfml_h16x2 h[4], l[4];
+    vfml_split2(t0[0], t0[1], h[0], l[0]);
+    vfml_split2(t0[2], t0[3], h[1], l[1]);
+    vfml_split2(t1[0], t1[1], h[2], l[2]);
+    vfml_split2(t1[2], t1[3], h[3], l[3]);
+    uint4 hv, lv;
+    hv.x = __builtin_bit_cast(unsigned, h[0]); hv.y = __builtin_bit_cast(unsigned, h[1]);
+    hv.z = __builtin_bit_cast(unsigned, h[2]); hv.w = __builtin_bit_cast(unsigned, h[3]);
+    lv.x = __builtin_bit_cast(unsigned, l[0]); lv.y = __builtin_bit_cast(unsigned, l[1]);
+    lv.z = __builtin_bit_cast(unsigned, l[2]); lv.w = __builtin_bit_cast(unsigned, l[3]);
+    char* o = rows + p * 128 + u * 32;
+    *reinterpret_cast<uint4*>(o) = hv;
+    *reinterpret_cast<uint4*>(o + 16) = lv;
+  }
+}
+
 // out[p] = bias + sum of the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3)
 __global__ void tapsum3x3_kernel(const float* __restrict__ t, int ld, const float* __restrict__ bias, int h, int w,
                                  int64_t total, f32x4* __restrict__ out) {
@@ -537,6 +564,15 @@ extern "C" int vfml_coords_update(float* coords1, const float* delta, int n, int
                      reinterpret_cast<hipStream_t>(stream), (f32x4*)coords1, (const f32x4*)delta, h, w, total, flow_a,
                      ld_a, flow_b, ld_b, fmt_b == VFML_FMT_S16 ? 1 : 0);
   return vfml_check_launch("vfml_coords_update");
+}
+
+extern "C" int vfml_flow_rows7(const float* flow, int n, int h, int w, float* rows, void* stream) {
+  VFML_REQUIRE(flow && rows && n > 0 && h > 0 && w > 0, "vfml_flow_rows7: bad argument");
+  VFML_REQUIRE(vfml_aligned16(flow) && (reinterpret_cast<uintptr_t>(rows) & 31u) == 0, "vfml_flow_rows7: flow 16-byte, rows 32-byte aligned");
+  const int64_t total = (int64_t)n * h * w;
+  hipLaunchKernelGGL(flow_rows7_kernel, dim3(grid_for(total * 4, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const f32x4*)flow, w, total, reinterpret_cast<char*>(rows));
+  return vfml_check_launch("vfml_flow_rows7");
 }
 
 extern "C" int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, void* stream) {

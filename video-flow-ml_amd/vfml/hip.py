@@ -119,6 +119,7 @@ def lib():
                                             c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+    L.vfml_flow_rows7.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
@@ -141,7 +142,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
-    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3",
+    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_flow_rows7",
     "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -502,6 +503,11 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
 
 def coords_init(coords1, n, h, w):
     _check(lib().vfml_coords_init(_ptr(_dev(coords1)), n, h, w, _stream()), "vfml_coords_init")
+
+
+def flow_rows7(flow, n, h, w, rows):
+    """rows[p] = the seven horizontal taps' flow quads of pixel p as 32 split-row channels (include/vfml.h vfml_flow_rows7)."""
+    _check(lib().vfml_flow_rows7(_ptr(_dev(flow)), n, h, w, _ptr(_dev(rows)), _stream()), "vfml_flow_rows7")
 
 
 def tapsum3x3(t, ld_t, bias, n, h, w, out):

@@ -99,6 +99,7 @@ class MOFNetHIP(_Holder):
             return self._packed
         P, cblock_names, cb64_names = {}, set(), set()
         cout_packed = {}       # layers whose packed matrix has another row count than their bias
+        rows7 = set()          # convf1 as a 7x1 convolution over the horizontal taps' rows
 
         def block_of(layer, c0, ctot, cout):
             """K-axis block of a split-row layer's weight planes: 64 channels where the layer runs one MFMA per product
@@ -130,13 +131,21 @@ class MOFNetHIP(_Holder):
                 # 3x3 convolution padded to a 32-column tile
                 w = w.permute(2, 3, 0, 1).reshape(36, cin, 1, 1).contiguous()
                 cout_packed[name] = 36
+            if (name.endswith(".encoder.convf1") and split and (cin, kh, kw) == (4, 7, 7)
+                    and not os.environ.get("VFML_NO_ROWS7")):        # (A/B switch)
+                # 7x7 over the 4-channel flow as 7x1 over 32 channels = the seven horizontal taps' quads per pixel
+                # (vfml_flow_rows7): [cout][kx*4 + c][ky][1], channels 28..31 zero
+                w7 = torch.zeros(cout, 32, 7, 1, device=device)
+                w7[:, :28, :, 0] = w.permute(0, 3, 1, 2).reshape(cout, 28, 7)
+                w = w7
+                rows7.add(name)
             if name.endswith(".tprop"):
                 # 1x1 conv over [prev | cur | next] motion features == 3x1 conv along the frame axis
                 w = w.reshape(cout, 3, cin // 3, 1).permute(0, 2, 1, 3)  # -> [cout, cin/3, kh=3, kw=1]
             # update-block convolutions read split-row activations (all but convf1, whose input is the
             # 4-channel f32 flow), and so do the encoders behind their 4-channel stem: those weights go in
             # channel-block K order (include/vfml.h)
-            cb = split and ((name.startswith("update_block.") and not name.endswith(".convf1")) or
+            cb = split and ((name.startswith("update_block.") and (not name.endswith(".convf1") or name in rows7)) or
                             (self._enc_split_rows() and (
                                 (name.split(".")[0] in ("fnet", "cnet") and name.count(".") > 1) or
                                 name in ("fnet.conv2", "cnet.conv2"))))
@@ -179,6 +188,7 @@ class MOFNetHIP(_Holder):
                                 hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP)
                     P[name] = (sw, b)
         self._tapsum = bool(cout_packed)
+        self._rows7 = bool(rows7)
         self._packed, self._packed_key = P, key
         self._graphs.clear()              # captured launches hold the old planes' addresses
         self._packed_serial += 1          # new weights: cached encoder outputs are stale
@@ -638,6 +648,7 @@ class MOFNetHIP(_Holder):
             flow4 = self._buf("flow4", MP * 4, dev)
             delta = self._buf("delta", MP * 4, dev)
             fh_taps = self._buf("fh_taps", MP * 36, dev)
+            frows = self._buf("flow_rows7", MP * 32, dev)
             coords1 = self._buf("coords1", MP * 4, dev)
 
             # ---- the update iterations + mask head + upsampling: a FIXED launch sequence for a given geometry,
@@ -681,8 +692,13 @@ class MOFNetHIP(_Holder):
                     hip.conv2d(c1, 256, 256, nm, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
                                in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc2"))
                     wgt, b = P[f"{ub}.encoder.convf1"]
-                    hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
-                               out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
+                    if self._rows7:
+                        hip.flow_rows7(flow4, nm, h, w, frows)
+                        hip.conv2d(frows, 32, 32, nm, h, w, wgt, b, 128, 7, 1, f1, 128, pad_h=3, epilogue=hip.EPI_RELU,
+                                   in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
+                    else:
+                        hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                                   out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
                     wgt, b = P[f"{ub}.encoder.convf2"]
                     hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf2"))
