@@ -213,6 +213,18 @@ class VideoFlowProcessor:
             tok = clip_token(clip)
             keys = [(tok, i, rect) for i in frame_ids]
             flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=keys, pick_only=self.PICK_ONLY)
+            # the frame after this one is what a job asks for next: its window's new frame goes through the encoders
+            # now, on a side stream beside this field's update iterations (vfml/network.py prefetch_frames)
+            if frame_idx + 1 < clip.shape[0] and hasattr(model, "prefetch_frames"):
+                nxt = self.window_indices(clip.shape[0], frame_idx + 1)
+                # (consecutive frames only: such a window is a VIEW of the clip - a gathered one would be produced on this
+                # stream, behind the iterations the prefetch is meant to run beside)
+                if (nxt != frame_ids and nxt == list(range(nxt[0], nxt[0] + len(nxt)))
+                        and max(nxt) <= getattr(clip, "_vfml_frames_ready", clip.shape[0]) - 1):
+                    nwin = take_frames(clip, nxt)
+                    if tile is not None:
+                        nwin = nwin[:, tile['y']:tile['y'] + tile['height'], tile['x']:tile['x'] + tile['width']]
+                    model.prefetch_frames(nwin, [(tok, i, rect) for i in nxt])
             return flows[0, flows.shape[1] // 2].permute(1, 2, 0)
         batch = (win.float() / 255.0).permute(0, 3, 1, 2).unsqueeze(0)
         return self.core.compute_flow_from_tensor(batch).permute(1, 2, 0)

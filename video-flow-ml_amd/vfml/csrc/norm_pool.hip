@@ -304,15 +304,23 @@ extern "C" int vfml_instnorm_finalize(const double* part, int n, int chunks, int
   // the encoders run outside any stream capture; calls on one stream, as the engine makes them, are ordered)
   constexpr int64_t SCRATCH = 1 << 20;
   static const int no_fold = getenv("VFML_NO_NORM_FOLD") ? atoi(getenv("VFML_NO_NORM_FOLD")) : 0;     // (A/B)
-  if (!no_fold && chunks >= 1024 && c % 8 == 0 && (int64_t)n * FOLD_SLICES * c * 16 <= SCRATCH) {
+  // (the route depends on chunks and c only - never on n: a frame's statistics are the same bits whether it is encoded
+  // alone or in a batch; batches larger than the scratch go through it a few frames at a time)
+  const int64_t per_frame = (int64_t)FOLD_SLICES * c * 16;
+  if (!no_fold && chunks >= 1024 && c % 8 == 0 && per_frame <= SCRATCH) {
     static double* scratch[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
       if (!scratch[dev] && hipMalloc(&scratch[dev], SCRATCH) != hipSuccess) scratch[dev] = nullptr;
       if (scratch[dev]) {
-        hipLaunchKernelGGL(instnorm_fold_kernel, dim3(n * (c / 8) * FOLD_SLICES), dim3(256), 0, st, part, chunks, c, scratch[dev]);
-        hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, st, (const double*)scratch[dev], n, FOLD_SLICES,
-                           c, hw, eps, stats);
+        const int nmax = (int)(SCRATCH / per_frame);
+        for (int n0 = 0; n0 < n; n0 += nmax) {
+          const int nb = n - n0 < nmax ? n - n0 : nmax;
+          hipLaunchKernelGGL(instnorm_fold_kernel, dim3(nb * (c / 8) * FOLD_SLICES), dim3(256), 0, st,
+                             part + (int64_t)n0 * chunks * c * 2, chunks, c, scratch[dev]);
+          hipLaunchKernelGGL(instnorm_final_kernel, dim3(nb * c), dim3(FINAL_THREADS), 0, st, (const double*)scratch[dev], nb,
+                             FOLD_SLICES, c, hw, eps, stats + (int64_t)n0 * c * 2);
+        }
         return vfml_check_launch("vfml_instnorm_finalize");
       }
     }

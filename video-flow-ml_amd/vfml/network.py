@@ -80,6 +80,9 @@ class MOFNetHIP(_Holder):
         self._ws = {}
         self._graphs = {}
         self._pyr_free = []
+        self._side = {}                # per device: the stream the next window's encoders run on (prefetch_frames)
+        self._prefetch_done = None     # event: the last prefetch's launches
+        self._pre_body = None          # event: the last field's inputs are ready, its iterations not yet queued
         import collections
         self._feat_cache = collections.OrderedDict()
 
@@ -424,6 +427,75 @@ class MOFNetHIP(_Holder):
         self._feat_cache.clear()
         self._pyr_free = []
 
+    def prefetch_frames(self, frames, frame_keys):
+        """The encoders a COMING window will need - feature maps / target planes of its frames, context maps of its centre
+        frames, whatever of them is not cached yet - queued on a side stream, behind the inputs of the field just launched
+        and BESIDE its update iterations: the encoders' short-K convolutions and HBM-bound norm passes fill what the
+        iterations' MFMA-bound launches leave idle (tails of half-empty rounds, memory bandwidth).  Same kernels, same
+        inputs: the cached results are the bits a later forward_u8 would compute itself.  frames: uint8 [N,H,W,3] of the
+        coming window, frame_keys as for forward_u8.
+
+        EXPERIMENT, OFF unless VFML_PREFETCH=1: at 1080p the fields computed with it differ from the serial ones in the
+        third digit and from run to run - some correlation-pyramid tiles of the field that runs BESIDE the prefetch come out
+        different (profiles/r02_kernel_anatomy.md section 7; unrelated kernels on a second stream, or this library's
+        convolutions on their own buffers, do not do that to a field; the cause was not found this round).  Serialised
+        behind the field (VFML_PREFETCH_DBG=serial) it is bit-identical, and pointless."""
+        if (frame_keys is None or self._pre_body is None or os.environ.get("VFML_PREFETCH", "0") != "1" or self.tri_frame):
+            return
+        cfg = self.cfg
+        N, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        if N < 3 or H % 8 or W % 8 or len(frame_keys) != N:
+            return
+        L, dev = cfg.corr_levels, frames.device
+        h, w = H // 8, W // 8
+        hl, wl = [h], [w]
+        for l in range(1, L):
+            hl.append(hl[-1] // 2)
+            wl.append(wl[-1] // 2)
+        Sl = [hl[l] * wl[l] for l in range(L)]
+        keys = [(k, H, W, L, self._plan_key(), self._packed_serial) for k in frame_keys]
+        need_f = [j for j in range(N) if ("f", keys[j]) not in self._feat_cache]
+        need_c = [j for j in range(1, N - 1) if ("c", keys[j]) not in self._feat_cache]
+        if not need_f and not need_c:
+            return
+        main = torch.cuda.current_stream(dev)
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        P = self._pack(dev)
+        dbg = os.environ.get("VFML_PREFETCH_DBG", "")
+        if "serial" in dbg:
+            side.wait_stream(main)
+        else:
+            side.wait_event(self._pre_body)
+        if "nof" in dbg:
+            need_f = []
+        if "noc" in dbg:
+            need_c = []
+        with torch.cuda.stream(side):
+            new = []
+            if need_f:
+                new += list(self._frame_features(frames, need_f, keys, H, W, P, dev, L, hl, wl, Sl).values())
+            if need_c:
+                new += list(self._frame_context(frames, need_c, keys, H, W, P, dev, h * w).values())
+            done = torch.cuda.Event()
+            done.record(side)
+        # the cached tensors were allocated on the side stream and will be read (and one day freed) under the main one
+
+        def walk(x):
+            if isinstance(x, torch.Tensor):
+                x.record_stream(main)
+            elif isinstance(x, (list, tuple)):
+                for y in x:
+                    walk(y)
+            elif isinstance(x, dict):
+                for y in x.values():
+                    walk(y)
+            elif hasattr(x, "planes") and isinstance(getattr(x, "planes"), torch.Tensor):
+                x.planes.record_stream(main)
+        walk(new)
+        self._prefetch_done = done
+
     def _pyramid_buffers(self, sizes, dev, limit):
         """Level buffers for a new correlation pyramid (5.6 GB at 1080p).  When the pyramid cache is at its
         limit the least recently used pyramid is retired FIRST and its buffers are handed to the new one:
@@ -546,6 +618,9 @@ class MOFNetHIP(_Holder):
         if (h >> (L - 1)) < 2 or (w >> (L - 1)) < 2:
             raise ValueError(f"frame {H}x{W} too small for a {L}-level correlation pyramid")
         dev = src.device
+        if self._prefetch_done is not None:      # a prefetch shares the encoders' workspaces and fills the caches read below
+            torch.cuda.current_stream(dev).wait_event(self._prefetch_done)
+            self._prefetch_done = None
         M = N - 2
         Pn = h * w          # cells per map
         MP = M * Pn
@@ -765,6 +840,8 @@ class MOFNetHIP(_Holder):
 
             gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(), vol16,
                     self._packed_serial, str(dev))
+            self._pre_body = torch.cuda.Event()
+            self._pre_body.record(torch.cuda.current_stream(dev))      # (what a prefetch of the next window waits for)
             self._run_body(body, gkey, dev)
             up = up_fixed.clone().view(nflows, H, W, 2)          # the caller owns its field; the fixed buffer is reused
             if pick_only and not self.tri_frame:

@@ -75,6 +75,7 @@ class ClipFeeder:
         self.clip._vfml_clip_token = (new_id(), "fed")
         # per-frame maxima, known at upload: MemFlow's value-range heuristic (memflow_inference_isolated.py:81-85)
         self.clip._vfml_frame_maxima = [None] * len(frames)
+        self.clip._vfml_frames_ready = 0
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # earlier readers of the old frames
 
@@ -82,6 +83,7 @@ class ClipFeeder:
         """Frames before `frame` will not be needed (a rank whose shard starts later in the clip): they are never
         uploaded.  Only moves forward."""
         self.next = max(self.next, min(frame, len(self.frames)))
+        self.clip._vfml_frames_ready = self.next
 
     def ensure(self, upto):
         upto = min(upto, len(self.frames) - 1)
@@ -93,6 +95,7 @@ class ClipFeeder:
                 self.clip[f] = torch.from_numpy(np.ascontiguousarray(self.frames[f]))
                 maxima[f] = float(self.frames[f].max())
             self.next = upto + 1
+            self.clip._vfml_frames_ready = self.next
             return
         last = None
         for f in range(self.next, upto + 1):
@@ -107,6 +110,7 @@ class ClipFeeder:
                 last.record(self.stream)
             self.events[r] = last
         self.next = upto + 1
+        self.clip._vfml_frames_ready = self.next      # frames [0, next) are (stream-ordered) in the clip: what a prefetch may read
         torch.cuda.current_stream(self.device).wait_event(last)    # (copies on one stream complete in order)
 
 
