@@ -18,7 +18,8 @@ long job (one new frame per field).  `engine_ms_per_step` is the same loop with 
 
 Extra objects on the line:
   roofline      dominant kernel, from a SEPARATE pass after the timed region (per-launch HIP events on the launch
-                stream perturb the timing, so they never run inside `value`): achieved algorithmic TFLOP/s vs the dense
+                stream perturb the timing, so they never run inside `value`; the encoder prefetch that otherwise runs
+                on a side stream beside the iterations is queued behind the field in this pass): achieved algorithmic TFLOP/s vs the dense
                 f16 MFMA peak / MFMAs per product; `traffic`: HBM-side bytes per launch from the PMC passes recorded
                 under profiles/ (a stored constant of that profile run, labelled so); `hbm_kernels`: the lookup
   cpu_baseline  the CPU oracle (oracle/mof_oracle.py, "port") timed on this box's host cores BEFORE the timed region on a
@@ -242,8 +243,17 @@ def main():
         e0 = time.perf_counter()
         if rank == 0:
             hip.profile_begin()
+        # (the next window's encoders normally run on a side stream BESIDE the update iterations, network.py
+        # prefetch_frames; here they queue behind the field so that every event-bracketed launch has the GPU to itself -
+        # a launch that shares the chip with another stream's kernels says nothing about the kernel)
+        dbg_before = os.environ.get("VFML_PREFETCH_DBG")
+        os.environ["VFML_PREFETCH_DBG"] = "serial"
         job(mine[per_rank - Pn:], collect=False)           # (every rank does the same work; only rank 0 records)
         torch.cuda.synchronize()
+        if dbg_before is None:
+            del os.environ["VFML_PREFETCH_DBG"]
+        else:
+            os.environ["VFML_PREFETCH_DBG"] = dbg_before
         t_prof = time.perf_counter() - e0
         if rank == 0:
             prof_hbm = hip.profile_end_hbm()
@@ -319,7 +329,8 @@ def main():
             "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "pass": f"separate pass over {Pn} further fields of the same job after the timed region, per-launch HIP "
-                    f"events on the launch stream ({1000.0 * t_prof / Pn:.2f} ms per field with the events in)",
+                    f"events on the launch stream, the next window's encoders queued behind the field instead of beside it "
+                    f"({1000.0 * t_prof / Pn:.2f} ms per field that way)",
             "share_of_pass": d["ms"] / (1000.0 * t_prof),
             "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                  "launches": v["launches"]} for k, v in prof.items()},

@@ -262,6 +262,36 @@ def test_full_size_properties_1080p_and_4k_tiles(gpu):
     torch.cuda.empty_cache()
 
 
+def test_prefetched_encoders_give_the_same_fields(gpu, monkeypatch):
+    """The encoders of the NEXT window run on a side stream beside this field's update iterations (network.py
+    prefetch_frames): the same kernels on the same inputs, so every field of a streamed 1080p clip is bit-identical to the
+    one computed without the prefetch - also the field whose iterations ran beside it.  (Round 2 found the fixed-radius
+    lookup returning different samples with an MFMA kernel on a second stream: profiles/r02_kernel_anatomy.md section 7.)"""
+    import contextlib
+    import io
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.synth import synthetic_clip
+    net, _ = _pair()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=5)
+    proc.core.model = net
+    frames = synthetic_clip(10, 1080, 1920)
+    clip = proc.upload_clip(frames)
+    order = [2, 3, 4, 5, 6, 7]
+    monkeypatch.setenv("VFML_PREFETCH", "0")
+    net.clear_feature_cache()
+    serial = [proc.compute_optical_flow_resident(clip, i).clone() for i in order]
+    for rep in range(3):
+        monkeypatch.setenv("VFML_PREFETCH", "1")
+        net.clear_feature_cache()
+        pre = [proc.compute_optical_flow_resident(clip, i).clone() for i in order]
+        torch.cuda.synchronize()
+        for i, a, b in zip(order, serial, pre):
+            assert torch.equal(a, b), f"field {i} (pass {rep}): {int((a != b).sum())} values differ, max {float((a - b).abs().max()):.3g} px"
+    net.clear_feature_cache()
+    torch.cuda.empty_cache()
+
+
 def test_bof_fields_batched_equal_fields_one_by_one(gpu):
     """`--vf-architecture bof`, seq 9: consecutive interior fields go through the tri-frame network four at a
     time (tri_batch); clip-edge fields, whose centre triples repeat frames, one by one.  Both orders of

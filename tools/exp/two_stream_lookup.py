@@ -1,9 +1,11 @@
-"""Open finding of round 2 (profiles/r02_kernel_anatomy.md section 7): vfml_corr_lookup returns slightly different windows for a
-few dozen of 32 400 queries (pyramid levels 2-3) while one of this library's MFMA convolution / GEMM kernels runs on ANOTHER
-stream - unrelated kernels (rocBLAS, copies) beside it, or this library's convolutions beside each other, change nothing.  The
-engine never runs its compute kernels on two streams (the encoder prefetch that would is off: VFML_PREFETCH=1).
+"""Finding of round 2 (profiles/r02_kernel_anatomy.md section 7): vfml_corr_lookup returned slightly different windows for a
+few dozen of 32 400 queries (pyramid levels 2-3) while one of this library's MFMA convolution / GEMM kernels ran on ANOTHER
+stream - a packed-f32 multiply reading a ds_read2 result straight behind its s_waitcnt (two_stream_lookup_diag.py shows
+which operand; fixed by `bilinear4` + -fno-slp-vectorize for flow_ops.hip).  This is the reproducer, now a regression check:
+every line must say 0/100.
 
-    python tools/exp/two_stream_lookup.py"""
+    python tools/exp/two_stream_lookup.py
+    VFML_LIB=<a library built with -DVFML_LOOKUP_OLD_ARITH> python tools/exp/two_stream_lookup.py     # the old behaviour"""
 import sys, os, math, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, ROOT)
@@ -42,7 +44,7 @@ og = torch.zeros(32400 * 8064, device="cuda")
 aggs["persistent GEMM (LDS-DMA) 32400x8040x256"] = lambda: hip.conv2d(rows, 256, 256, 1, 1, 32400, wg, None, 8040, 1, 1, og, 8064, in_fmt=hip.FMT_S16)
 side = torch.cuda.Stream()
 for fmt, fname in ((hip.FMT_S16, "S16 out"), (hip.FMT_F32, "f32 out")):
-    lookup(fmt); torch.cuda.synchronize(); ref = out.clone()
+    out.zero_(); lookup(fmt); torch.cuda.synchronize(); ref = out.clone()
     for name, fn in aggs.items():
         fn(); torch.cuda.synchronize(); bad = 0
         for it in range(10):

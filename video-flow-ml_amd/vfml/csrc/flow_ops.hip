@@ -30,6 +30,20 @@ struct LookupArgs {
   int vol16;     // the pyramids hold one f16 per element (VFML_FMT_F16; fixed-radius kernels only)
 };
 
+// grid_sample's bilinear mix nw*(1-fx)(1-fy) + ne*fx(1-fy) + sw*(1-fx)fy + se*fx*fy as ONE explicit chain of fused
+// multiply-adds, shared by both lookup kernels so that they agree bit for bit whatever hipcc would contract on its own.
+// It also keeps the mix out of v_pk_mul_f32: left to the vectoriser, the fixed-radius kernel multiplied the (sw, se) pair
+// as a packed op straight after the s_waitcnt of its ds_read2_b32, and with one of this library's MFMA kernels on a second
+// stream that packed multiply read a stale `sw` register in lanes 48-63 a few dozen times per launch
+// (profiles/r02_kernel_anatomy.md section 7, tools/exp/two_stream_lookup_diag.py).
+__device__ __forceinline__ float bilinear4(float nw, float ne, float sw, float se, float wx0, float fx, float wy0, float fy) {
+  float v = ne * (fx * wy0);
+  v = __builtin_fmaf(nw, wx0 * wy0, v);
+  v = __builtin_fmaf(sw, wx0 * fy, v);
+  v = __builtin_fmaf(se, fx * fy, v);
+  return v;
+}
+
 // One wave per query.  Per level the window's (2r+1)^2 bilinear samples all share the same
 // fractional offset, so they are blends of one (2r+2)^2 integer-grid patch: the wave gathers the
 // patch (zero outside the level) into LDS, then each lane produces output channels
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
     const float* p = &patch[wv][l][j * side + i];
     // grid_sample's bilinear: nw*(1-fx)(1-fy) + ne*fx(1-fy) + sw*(1-fx)fy + se*fx*fy
     const float wx0 = 1.f - fx, wy0 = 1.f - fy;
-    const float v = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[side] * (wx0 * fy) + p[side + 1] * (fx * fy);
+    const float v = bilinear4(p[0], p[1], p[side], p[side + 1], wx0, fx, wy0, fy);
     if (a.out16) {
       vfml_h16x2 hh, ll;
       vfml_split2(v, 0.f, hh, ll);
@@ -135,31 +149,36 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
       lh[l] = a.hl[l];
     }
     // all texels of the query are requested before the first one is used: NLOAD independent loads in flight per
-    // lane (a loop that stores each value to LDS before the next load pays the HBM latency NLOAD times)
+    // lane.  The loads are UNCONDITIONAL (window cells outside the level read its clamped edge texel and are zeroed
+    // by a select afterwards): behind a per-lane bounds branch hipcc waits vmcnt(0) at every join, i.e. it pays the
+    // HBM latency NLOAD times.  They are also explicitly GLOBAL loads: a pointer picked among several by selects
+    // loses its address space and becomes flat_load, which returned wrong texels for a few dozen queries per launch
+    // whenever another of this library's MFMA kernels ran on a second stream (profiles/r02_kernel_anatomy.md 7).
     constexpr int NLOAD = (FIXED_LEVELS * PSZ + 63) / 64;
     float val[NLOAD];
+    bool ok[NLOAD];
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       const int e = lane + 64 * it;
-      val[it] = 0.f;
-      if (e < total) {
-        const int l = e / PSZ;
-        const int idx = e - l * PSZ;
-        const int py = idx / SIDE, px = idx - py * SIDE;
-        const float inv = 1.0f / (float)(1 << l);
-        const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
-        const int x0 = (int)fminf(fmaxf(floorf(x), -65536.f), 65536.f) - R;
-        const int y0 = (int)fminf(fmaxf(floorf(y), -65536.f), 65536.f) - R;
-        const int xx = x0 + px, yy = y0 + py;
-        const char* base = l == 0 ? lp[0] : (l == 1 ? lp[1] : (l == 2 ? lp[2] : lp[3]));
-        const int wl = l == 0 ? lw[0] : (l == 1 ? lw[1] : (l == 2 ? lw[2] : lw[3]));
-        const int hl = l == 0 ? lh[0] : (l == 1 ? lh[1] : (l == 2 ? lh[2] : lh[3]));
-        if (xx >= 0 && xx < wl && yy >= 0 && yy < hl) {
-          if constexpr (VOL16) val[it] = (float)reinterpret_cast<const _Float16*>(base)[yy * wl + xx];
-          else val[it] = reinterpret_cast<const float*>(base)[yy * wl + xx];
-        }
-      }
+      const bool in = e < total;
+      const int l = in ? e / PSZ : 0;
+      const int idx = e - l * PSZ;
+      const int py = idx / SIDE, px = idx - py * SIDE;
+      const float inv = 1.0f / (float)(1 << l);
+      const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
+      const int x0 = (int)fminf(fmaxf(floorf(x), -65536.f), 65536.f) - R;
+      const int y0 = (int)fminf(fmaxf(floorf(y), -65536.f), 65536.f) - R;
+      const int xx = x0 + px, yy = y0 + py;
+      const char* base = l == 0 ? lp[0] : (l == 1 ? lp[1] : (l == 2 ? lp[2] : lp[3]));
+      const int wl = l == 0 ? lw[0] : (l == 1 ? lw[1] : (l == 2 ? lw[2] : lw[3]));
+      const int hl = l == 0 ? lh[0] : (l == 1 ? lh[1] : (l == 2 ? lh[2] : lh[3]));
+      ok[it] = in && xx >= 0 && xx < wl && yy >= 0 && yy < hl;
+      const int at = min(max(yy, 0), hl - 1) * wl + min(max(xx, 0), wl - 1);
+      if constexpr (VOL16) val[it] = (float)((const __attribute__((address_space(1))) _Float16*)base)[at];
+      else val[it] = ((const __attribute__((address_space(1))) float*)base)[at];
     }
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) val[it] = ok[it] ? val[it] : 0.f;
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       const int e = lane + 64 * it;
@@ -190,8 +209,12 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
         const float fx = frac[wv][l][0], fy = frac[wv][l][1];
         const float* p = &patch[wv][l][j * SIDE + i];
         const float wx0 = 1.f - fx, wy0 = 1.f - fy;
-        // (same expression, same order as the generic kernel: results are bit-identical)
+        // (the same fused chain as the generic kernel: results are bit-identical)
+#ifdef VFML_LOOKUP_OLD_ARITH
         v[k] = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[SIDE] * (wx0 * fy) + p[SIDE + 1] * (fx * fy);
+#else
+        v[k] = bilinear4(p[0], p[1], p[SIDE], p[SIDE + 1], wx0, fx, wy0, fy);
+#endif
       }
     }
     if (OUT16) {

@@ -44,6 +44,13 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+# Per-source compiler flags.  flow_ops.hip is built without the SLP vectoriser: left on, it pairs the bilinear mix of the
+# correlation lookup into v_pk_mul_f32 / v_pk_add_f32 reading ds_read results straight behind their s_waitcnt, and on gfx950
+# such a packed op read a stale register in lanes 48-63 whenever one of this library's MFMA kernels ran on another stream
+# (profiles/r02_kernel_anatomy.md section 7; tools/exp/two_stream_lookup_diag.py shows it, scan_pk_after_lds.py lists the sites).
+EXTRA_FLAGS = {"flow_ops.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into libvfml_hip.so (in-tree). Cross-compiles without a GPU."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
@@ -61,7 +68,8 @@ def build(force=False, verbose=False):
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
-            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + [
+                "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))
@@ -70,11 +78,6 @@ def build(force=False, verbose=False):
             raise subprocess.CalledProcessError(p.returncode, cmd)
     cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + [
         os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

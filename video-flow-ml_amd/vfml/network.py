@@ -435,12 +435,12 @@ class MOFNetHIP(_Holder):
         inputs: the cached results are the bits a later forward_u8 would compute itself.  frames: uint8 [N,H,W,3] of the
         coming window, frame_keys as for forward_u8.
 
-        EXPERIMENT, OFF unless VFML_PREFETCH=1: at 1080p the fields computed with it differ from the serial ones in the
-        third digit and from run to run - some correlation-pyramid tiles of the field that runs BESIDE the prefetch come out
-        different (profiles/r02_kernel_anatomy.md section 7; unrelated kernels on a second stream, or this library's
-        convolutions on their own buffers, do not do that to a field; the cause was not found this round).  Serialised
-        behind the field (VFML_PREFETCH_DBG=serial) it is bit-identical, and pointless."""
-        if (frame_keys is None or self._pre_body is None or os.environ.get("VFML_PREFETCH", "0") != "1" or self.tri_frame):
+        ON by default (VFML_PREFETCH=0 turns it off; VFML_PREFETCH_DBG=serial queues the same work BEHIND the field -
+        what bench.py's per-launch roofline pass does, so that every timed launch has the GPU to itself).  Fields are
+        bit-identical with and without it (tests/test_gpu_e2e.py::test_prefetched_encoders_give_the_same_fields); they were
+        not while the fixed-radius lookup mixed its samples with a packed-f32 op straight behind a ds_read, which reads a
+        stale register when another kernel's MFMAs share the SIMD (profiles/r02_kernel_anatomy.md section 7)."""
+        if (frame_keys is None or self._pre_body is None or os.environ.get("VFML_PREFETCH", "1") == "0" or self.tri_frame):
             return
         cfg = self.cfg
         N, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
