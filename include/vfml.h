@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 21
+#define VFML_ABI_VERSION 22
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -225,12 +225,19 @@ int vfml_avgpool2x2(const float* x, int n, int h, int w, int c, float* out, void
  * samples x+d[i], y+d[j]).
  *   pyr[m*levels+l] : float [q_per_map][ld[l]]  (columns = hl[l]*wl[l] targets, row-major); host array
  *                     of device pointers - each problem's pyramid may live in its own allocation
+ *   vol_tile        : 0, or tws + 16 * ths: every level image is stored as tiles of 2^tws x 2^ths texels (tile after
+ *                     tile, left to right then down; a tile row-major; edge tiles whole, so ld[l] >= the tiles' texels),
+ *                     and so is the query grid that orders the ROWS: query q = (y, x) of the hl[0] x wl[0] grid reads
+ *                     row tile_position(y, x) (q_per_map == hl[0]*wl[0]; rows of pad positions are never read).  What the
+ *                     volume GEMM writes when both its operands' rows are in that order (the engine: 4 x 8 tiles - a
+ *                     lookup window then lies in ~8 lines of 128 bytes instead of ~13)
  *   coords          : float [nmaps*q_per_map][ld_coords], x at +0, y at +1
  *   out             : [nmaps*q_per_map][ld_out], levels*(2r+1)^2 channels written from out
  * Replaces: F.grid_sample(align_corners=True) x levels. */
 int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl,
                      const int32_t* ld, int levels, int radius, int nmaps, int q_per_map,
-                     const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
+                     const float* coords, int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile,
+                     void* stream);
 /* out_fmt VFML_FMT_S16: channels are written as split rows; the channel count is rounded up to a
  * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0).
  * vol_fmt VFML_FMT_F32, or VFML_FMT_F16: the pyramids hold one f16 per element (ld in elements; radius 3 or 4, at most four
@@ -243,7 +250,7 @@ int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* 
  * kernel arguments: no host buffer has to outlive the call). */
 int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                               int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
-                              float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
+                              float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream);
 int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream);
 
 /* The 7x7 convolution over the 4-channel flow map (motion encoder, convf1) as a 7x1 convolution over 32 channels: this pass

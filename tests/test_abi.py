@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), f"{n} declared in include/vfml.h but not exported"
     assert sorted(hip.EXPORTS) == names
     lib.vfml_abi_version.restype = ctypes.c_int
-    assert lib.vfml_abi_version() == 21
+    assert lib.vfml_abi_version() == 22
 
 
 def test_argument_validation_needs_no_gpu():
@@ -36,7 +36,7 @@ def test_argument_validation_needs_no_gpu():
     assert b"null" in L.vfml_last_error()
     assert L.vfml_conv2d(None, None) != 0
     assert L.vfml_instnorm_workspace_bytes(2, 1024 * 3 + 1, 64) == 2 * 4 * 64 * 2 * 8
-    assert L.vfml_corr_lookup(None, None, None, None, 4, 4, 1, 1, None, 4, None, 324, 0, 0, None) != 0
+    assert L.vfml_corr_lookup(None, None, None, None, 4, 4, 1, 1, None, 4, None, 324, 0, 0, 0, None) != 0
 
 
 def test_conv_desc_layout_matches_header():

@@ -652,6 +652,48 @@ def test_corr_lookup_integer_coords_is_exact_gather(gpu):
             assert got[q, i, j].item() == want
 
 
+@pytest.mark.parametrize("radius,levels,vol16,out16", [(4, 4, False, True), (4, 4, True, False), (3, 3, False, False), (2, 2, False, False)])
+@pytest.mark.parametrize("tws,ths", [(2, 3), (3, 2), (0, 1)])
+def test_corr_lookup_reads_tiled_volumes(gpu, radius, levels, vol16, out16, tws, ths):
+    """vol_tile (include/vfml.h): level images stored as 2^tws x 2^ths tiles under rows in the tile order of the query grid
+    give bit for bit the windows of the row-major volume - fixed-radius kernels (f32 / f16 volumes, f32 / split-row
+    output) and the generic one (radius 2); ragged sizes, so edge tiles are partly empty (filled with NaN: never read)."""
+    from vfml import hip
+    h, w = 21, 27
+    P = h * w
+    g = torch.Generator().manual_seed(77)
+    hl, wl = [h >> l for l in range(levels)], [w >> l for l in range(levels)]
+    ld = [(a * b + 31) // 32 * 32 for a, b in zip(hl, wl)]
+    vt = hip.VolTile(tws, ths)
+    dt = torch.float16 if vol16 else torch.float32
+    plain, tiled, ldt = [], [], []
+    for l in range(levels):
+        v = torch.randn(P, hl[l] * wl[l], generator=g).to(dt)
+        t = torch.full((P, ld[l]), float("nan"), dtype=dt)
+        t[:, :hl[l] * wl[l]] = v
+        plain.append(t.cuda().reshape(-1))
+        n = vt.count(hl[l], wl[l])
+        ldt.append((n + 31) // 32 * 32)
+        cols = torch.full((P, ldt[-1]), float("nan"), dtype=dt)
+        cols[:, vt.position(hl[l], wl[l], "cpu")] = v
+        rows = torch.full((vt.count(h, w), ldt[-1]), float("nan"), dtype=dt)
+        rows[vt.position(h, w, "cpu")] = cols
+        tiled.append(rows.cuda().reshape(-1))
+    coords = (torch.rand(P, 4, generator=g) * torch.tensor([w, h, w, h]) + torch.randn(P, 4, generator=g) * 3.0).cuda().reshape(-1)
+    nch = levels * (2 * radius + 1) ** 2
+    ldo = (nch + 7) // 8 * 8
+    fmt = hip.FMT_S16 if out16 else hip.FMT_F32
+    vf = hip.FMT_F16 if vol16 else hip.FMT_F32
+    a = torch.zeros(P * ldo, device=gpu)
+    b = torch.zeros(P * ldo, device=gpu)
+    hip.corr_lookup(plain, hl, wl, ld, radius, P, coords, 0, 4, a, 0, ldo, out_fmt=fmt, vol_fmt=vf)
+    hip.corr_lookup(tiled, hl, wl, ldt, radius, P, coords, 0, 4, b, 0, ldo, out_fmt=fmt, vol_fmt=vf, vol_tile=vt.code)
+    assert torch.isfinite(a.view(P, ldo)[:, :nch] if not out16 else a.view(torch.float16)).all()
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="whole tiles"):
+        hip.corr_lookup(tiled, hl, wl, ld, radius, P, coords, 0, 4, b, 0, ldo, out_fmt=fmt, vol_fmt=vf, vol_tile=vt.code + 16 * 3)
+
+
 def test_coords_and_upsample(gpu):
     from oracle import mof_oracle as mo
     from vfml import hip

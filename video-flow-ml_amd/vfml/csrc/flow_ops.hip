@@ -28,7 +28,17 @@ struct LookupArgs {
   float* out; int ld_out;
   int out16;
   int vol16;     // the pyramids hold one f16 per element (VFML_FMT_F16; fixed-radius kernels only)
+  int tws, ths;  // vol_tile: a level image (and the query grid that orders the rows) stored in (1<<tws) x (1<<ths) tiles; 0, 0: row-major
+  int qw;        // width of the query grid (= wl[0]) when tiled: query q reads volume row tiled_at(q / qw, q % qw)
 };
+
+// Position of texel (y, x) of a w-wide image stored as (1<<tws) x (1<<ths) tiles, tile after tile, each tile row-major
+// (tws = ths = 0: plain row-major).  A (2r+2)^2 lookup window then lies in ~8 128-byte lines instead of ~13 (ten 40-byte row
+// segments): the lookup is bound by the lines it drags in, not by the texels it uses (tools/exp/lookup_tiled.py).
+__device__ __forceinline__ int tiled_at(int y, int x, int w, int tws, int ths) {
+  const int tpr = (w + (1 << tws) - 1) >> tws;
+  return ((((y >> ths) * tpr + (x >> tws)) << (tws + ths)) + ((y & ((1 << ths) - 1)) << tws) + (x & ((1 << tws) - 1)));
+}
 
 // grid_sample's bilinear mix nw*(1-fx)(1-fy) + ne*fx(1-fy) + sw*(1-fx)fy + se*fx*fy as ONE explicit chain of fused
 // multiply-adds, shared by both lookup kernels so that they agree bit for bit whatever hipcc would contract on its own.
@@ -64,6 +74,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
     const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
     const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
     const int total = a.levels * psz;
+    const int qrow = (a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq;
     for (int e = lane; e < total; e += 64) {
       const int l = e / psz;
       const int idx = e - l * psz;
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
       const int xx = x0 + px, yy = y0 + py;
       float v = 0.f;
       if (xx >= 0 && xx < a.wl[l] && yy >= 0 && yy < a.hl[l])
-        v = (a.table ? a.table[map * a.levels + l] : a.pyr[map][l])[(int64_t)qq * a.ld[l] + (int64_t)yy * a.wl[l] + xx];
+        v = (a.table ? a.table[map * a.levels + l] : a.pyr[map][l])[(int64_t)qrow * a.ld[l] + tiled_at(yy, xx, a.wl[l], a.tws, a.ths)];
       patch[wv][l][idx] = v;
       if (idx == 0) {
         frac[wv][l][0] = x - fx0;
@@ -139,11 +150,12 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
     const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
     const int total = a.levels * PSZ;
     constexpr int ES = VOL16 ? 2 : 4;        // bytes per texel of the volume
+    const int qrow = (a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq;
     const char* lp[FIXED_LEVELS];
     int lw[FIXED_LEVELS], lh[FIXED_LEVELS];
 #pragma unroll
     for (int l = 0; l < FIXED_LEVELS; ++l) {
-      lp[l] = l < a.levels ? reinterpret_cast<const char*>(a.table ? a.table[map * a.levels + l] : a.pyr[map][l]) + (int64_t)qq * a.ld[l] * ES
+      lp[l] = l < a.levels ? reinterpret_cast<const char*>(a.table ? a.table[map * a.levels + l] : a.pyr[map][l]) + (int64_t)qrow * a.ld[l] * ES
                            : nullptr;
       lw[l] = a.wl[l];
       lh[l] = a.hl[l];
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
       const int wl = l == 0 ? lw[0] : (l == 1 ? lw[1] : (l == 2 ? lw[2] : lw[3]));
       const int hl = l == 0 ? lh[0] : (l == 1 ? lh[1] : (l == 2 ? lh[2] : lh[3]));
       ok[it] = in && xx >= 0 && xx < wl && yy >= 0 && yy < hl;
-      const int at = min(max(yy, 0), hl - 1) * wl + min(max(xx, 0), wl - 1);
+      const int at = tiled_at(min(max(yy, 0), hl - 1), min(max(xx, 0), wl - 1), wl, a.tws, a.ths);
       if constexpr (VOL16) val[it] = (float)((const __attribute__((address_space(1))) _Float16*)base)[at];
       else val[it] = ((const __attribute__((address_space(1))) float*)base)[at];
     }
@@ -417,27 +429,27 @@ extern "C" int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, v
 
 static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
                             const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream);
+                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream);
 
 extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                 int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
-                                float* out, int ld_out, int out_fmt, int vol_fmt, void* stream) {
+                                float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream) {
   VFML_REQUIRE(pyr, "vfml_corr_lookup: null pointer");
   return corr_lookup_impl(pyr, nullptr, hl, wl, ld, levels, radius, nmaps, q_per_map, coords, ld_coords, out, ld_out, out_fmt,
-                          vol_fmt, stream);
+                          vol_fmt, vol_tile, stream);
 }
 
 extern "C" int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                          int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                                         int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream) {
+                                         int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream) {
   VFML_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7u) == 0, "vfml_corr_lookup_indirect: null / misaligned table");
   return corr_lookup_impl(nullptr, table, hl, wl, ld, levels, radius, nmaps, q_per_map, coords, ld_coords, out, ld_out,
-                          out_fmt, vol_fmt, stream);
+                          out_fmt, vol_fmt, vol_tile, stream);
 }
 
 static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
                             const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, void* stream) {
+                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream) {
   VFML_REQUIRE(nmaps >= 1 && nmaps <= MAX_MAPS && q_per_map > 0, "vfml_corr_lookup: nmaps=%d out of [1,%d] or empty maps", nmaps, MAX_MAPS);
   const int nq = nmaps * q_per_map;
   VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
@@ -467,6 +479,14 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
     }
   }
   for (int l = levels; l < MAX_LEVELS; ++l) a.hl[l] = a.wl[l] = a.ld[l] = 0;
+  a.tws = vol_tile & 15; a.ths = (vol_tile >> 4) & 15; a.qw = wl[0];
+  VFML_REQUIRE(vol_tile >= 0 && vol_tile < 256 && a.tws <= 6 && a.ths <= 6, "vfml_corr_lookup: vol_tile = tws + 16 * ths with tws, ths <= 6");
+  if (vol_tile) {
+    VFML_REQUIRE(q_per_map == hl[0] * wl[0], "vfml_corr_lookup: a tiled volume orders its rows by the level-0 grid (q_per_map == hl[0] * wl[0])");
+    for (int l = 0; l < levels; ++l)
+      VFML_REQUIRE((int64_t)ld[l] >= (int64_t)(((hl[l] - 1) >> a.ths) + 1) * (((wl[l] - 1) >> a.tws) + 1) << (a.tws + a.ths),
+                   "vfml_corr_lookup: ld[%d]=%d is less than the whole tiles of a %d x %d level", l, ld[l], wl[l], hl[l]);
+  }
   a.levels = levels; a.radius = radius; a.nq = nq; a.q_per_map = q_per_map;
   a.coords = coords; a.ld_coords = ld_coords; a.out = out; a.ld_out = ld_out;
   const dim3 grid((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), block(64 * LOOKUP_WAVES);

@@ -117,9 +117,10 @@ def lib():
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                   c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+                                   c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     L.vfml_corr_lookup_indirect.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
-                                            c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+                                            c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_void_p]
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_flow_rows7.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
@@ -135,7 +136,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 21:
+    if L.vfml_abi_version() != 22:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -470,18 +471,19 @@ def ptr_table_set(table, tensors):
 
 
 def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coords, out, out_off, ld_out,
-                out_fmt=FMT_F32, table=None, nmaps=None, vol_fmt=FMT_F32):
+                out_fmt=FMT_F32, table=None, nmaps=None, vol_fmt=FMT_F32, vol_tile=0):
     """pyrs: list (one entry per query map) of lists (one flat float32 device tensor per level, rows =
     that map's q_per_map queries).  Queries / coords / out rows are ordered map-major.
     table (with nmaps): instead of `pyrs`, an int64 device tensor holding the same pointers, map-major
-    (ptr_table_set), read when the kernel runs (vfml_corr_lookup_indirect)."""
+    (ptr_table_set), read when the kernel runs (vfml_corr_lookup_indirect).
+    vol_tile: 0 (row-major level images, rows in query order) or VolTile.code (include/vfml.h)."""
     L = len(hl)
     if table is not None:
         def launch():
             _check(lib().vfml_corr_lookup_indirect(c_void_p(table.data_ptr()), (c_int32 * L)(*hl), (c_int32 * L)(*wl),
                                                    (c_int32 * L)(*ld), L, radius, nmaps, q_per_map,
                                                    _ptr(_dev(coords), coords_off), ld_coords, _ptr(_dev(out), out_off),
-                                                   ld_out, out_fmt, vol_fmt, _stream()), "vfml_corr_lookup_indirect")
+                                                   ld_out, out_fmt, vol_fmt, vol_tile, _stream()), "vfml_corr_lookup_indirect")
     else:
         if pyrs and torch.is_tensor(pyrs[0]):
             pyrs = [pyrs]
@@ -491,7 +493,7 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
         def launch():
             _check(lib().vfml_corr_lookup(ptrs, (c_int32 * L)(*hl), (c_int32 * L)(*wl), (c_int32 * L)(*ld), L, radius,
                                           nmaps, q_per_map, _ptr(_dev(coords), coords_off), ld_coords,
-                                          _ptr(_dev(out), out_off), ld_out, out_fmt, vol_fmt, _stream()), "vfml_corr_lookup")
+                                          _ptr(_dev(out), out_off), ld_out, out_fmt, vol_fmt, vol_tile, _stream()), "vfml_corr_lookup")
     if _PROFILE_HBM is None:
         launch()
         return
@@ -502,6 +504,39 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
     # algorithmic bytes: per query and level the (2r+2)^2 integer-grid patch in, (2r+1)^2 samples out
     q = nmaps * q_per_map
     _PROFILE_HBM.append(("corr_lookup", q * L * ((2 * radius + 2) ** 2 * (2.0 if vol_fmt == FMT_F16 else 4.0) + (2 * radius + 1) ** 2 * 4.0), e0, e1))
+
+
+class VolTile:
+    """Tiled layout of the correlation volume (include/vfml.h vfml_corr_lookup, vol_tile): level images - and the level-0
+    grid that orders the volume's rows - stored as 2^tws x 2^ths tiles.  The volume GEMM produces it for free when the rows
+    of both its operands are in tile order: `position(h, w)` is where each row-major pixel goes, `count(h, w)` how many rows
+    the whole tiles take (positions no pixel maps to are zero rows: their volume entries are never read)."""
+
+    def __init__(self, tws, ths):
+        self.tws, self.ths = tws, ths
+        self.code = tws + 16 * ths
+        self._pos = {}
+
+    def count(self, h, w):
+        return ((((h - 1) >> self.ths) + 1) * (((w - 1) >> self.tws) + 1)) << (self.tws + self.ths)
+
+    def position(self, h, w, dev):
+        key = (h, w, str(dev))
+        if key not in self._pos:
+            y = torch.arange(h, device=dev, dtype=torch.int64).view(h, 1)
+            x = torch.arange(w, device=dev, dtype=torch.int64).view(1, w)
+            tpr = ((w - 1) >> self.tws) + 1
+            pos = ((((y >> self.ths) * tpr + (x >> self.tws)) << (self.tws + self.ths))
+                   + ((y & ((1 << self.ths) - 1)) << self.tws) + (x & ((1 << self.tws) - 1)))
+            self._pos[key] = pos.reshape(-1).contiguous()
+        return self._pos[key]
+
+    def rows(self, x, h, w, c):
+        """x: flat [h*w*c] row-major pixels -> flat [count(h, w)*c] in tile order, zero rows where no pixel lands."""
+        n = self.count(h, w)
+        out = torch.zeros(n, c, device=x.device, dtype=x.dtype)
+        out.index_copy_(0, self.position(h, w, x.device), x.view(h * w, c))
+        return out.view(-1)
 
 
 def coords_init(coords1, n, h, w):

@@ -253,7 +253,19 @@ class MOFNetHIP(_Holder):
         if vol not in ("f32", "f16"):
             raise ValueError(f"cfg.corr_volume must be 'f32' or 'f16', got {vol!r}")
         key = (p, tuple(sorted((k, str(v)) for k, v in (getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
+        if self._tile() is None:
+            key = (key, "row-major")
         return key if vol == "f32" else (key, vol)
+
+    _VOL_TILE = hip.VolTile(2, 3)
+
+    def _tile(self):
+        """Layout of the correlation volumes: 4 x 8 tiles (hip.VolTile) on the split-row path - a lookup window then lies in
+        ~8 lines of 128 bytes instead of ~13, 149 -> 107 us per lookup at 1080p (tools/exp/lookup_tiled.py) - for the price
+        of whole edge tiles (+3.4 % GEMM columns at 1080p).  VFML_VOL_TILE=0: row-major (A/B switch; same fields)."""
+        if not self._split() or os.environ.get("VFML_VOL_TILE", "1") == "0":
+            return None
+        return self._VOL_TILE
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, name, numel, device, dtype=torch.float32, zero=False):
@@ -475,7 +487,7 @@ class MOFNetHIP(_Holder):
         with torch.cuda.stream(side):
             new = []
             if need_f:
-                new += list(self._frame_features(frames, need_f, keys, H, W, P, dev, L, hl, wl, Sl).values())
+                new += list(self._frame_features(frames, need_f, keys, H, W, P, dev, L, hl, wl, Sl, vt=self._tile()).values())
             if need_c:
                 new += list(self._frame_context(frames, need_c, keys, H, W, P, dev, h * w).values())
             done = torch.cuda.Event()
@@ -522,9 +534,11 @@ class MOFNetHIP(_Holder):
             oldest = next(k for k in self._feat_cache if k[0] == kind)
             del self._feat_cache[oldest]
 
-    def _frame_features(self, src, sel, keys, H, W, P, dev, L, hl, wl, Sl):
+    def _frame_features(self, src, sel, keys, H, W, P, dev, L, hl, wl, Sl, vt=None):
         """Feature map + target pyramid of frames `sel` of the window.
-        Returns {j: (fmap [Pn*256] f32, [target operand per level])}."""
+        Returns {j: (fmap [Pn*256] f32, [target operand per level])}.
+        vt (hip.VolTile): both operands' rows in tile order (zero rows at the positions no pixel has), so that the volume
+        GEMMs write tiled level images under tile-ordered rows."""
         D = self.cfg.feat_dim
         split = self._split()
         out, todo = {}, []
@@ -550,16 +564,23 @@ class MOFNetHIP(_Holder):
                 tg = []
                 for l in range(L):
                     f = levels[l][i * Sl[l] * D:(i + 1) * Sl[l] * D]
+                    nl = Sl[l]
+                    if vt is not None:
+                        f, nl = vt.rows(f, hl[l], wl[l], D), vt.count(hl[l], wl[l])
                     # features are O(1): x16 keeps the lo halves of the split normal
-                    tg.append(hip.SplitWeight(Sl[l], D, dev).fill(f, scale=16.0) if split else f)
+                    tg.append(hip.SplitWeight(nl, D, dev).fill(f, scale=16.0) if split else f)
                 fm = fmap[i * Pn * D:(i + 1) * Pn * D]
+                if vt is not None:
+                    fm, Pn_rows = vt.rows(fm, hl[0], wl[0], D), vt.count(hl[0], wl[0])
+                else:
+                    Pn_rows = Pn
                 if split:
                     # the GEMM's A operand in split rows, made once per frame - of the SAME x16 copy the target
                     # planes are split from, so that a frame's hi / lo halves are the same numbers on either
                     # side of a correlation GEMM (then <a, b> and <b, a> are the same products, and with
                     # VFML_CONV_SWAP_CROSS the same sums: a volume and its transpose are bit-identical)
-                    fm16 = torch.empty(Pn * D, device=dev)
-                    hip.to_s16(fm, Pn, D, D, fm16, D, scale=self.FMAP_ROW_SCALE)
+                    fm16 = torch.empty(Pn_rows * D, device=dev)
+                    hip.to_s16(fm, Pn_rows, D, D, fm16, D, scale=self.FMAP_ROW_SCALE)
                     fm = fm16
                 ent = (fm, tg)
                 out[j] = ent
@@ -636,19 +657,29 @@ class MOFNetHIP(_Holder):
                 hl.append(hl[-1] // 2)
                 wl.append(wl[-1] // 2)
             Sl = [hl[l] * wl[l] for l in range(L)]
-            ldl = [(s + 31) // 32 * 32 for s in Sl]
+            # volume geometry: Nl columns per level, Pv rows - the pixels, or the whole tiles of a tiled volume (_tile)
+            VT = self._tile()
+            Nl = [VT.count(hl[l], wl[l]) for l in range(L)] if VT is not None else Sl
+            Pv = Nl[0]
+            TILE = VT.code if VT is not None else 0
             # cfg.corr_volume 'f16': the pyramids as one f16 per value, written by the GEMM form (which needs every level's
             # width a multiple of 4 and split-row query features) - other geometries keep f32 volumes
-            vol16 = (getattr(cfg, "corr_volume", "f32") == "f16" and AF == hip.FMT_S16 and Pn % 4 == 0
-                     and all(s % 4 == 0 for s in Sl))
+            vol16 = (getattr(cfg, "corr_volume", "f32") == "f16" and AF == hip.FMT_S16 and Pv % 4 == 0
+                     and all(s % 4 == 0 for s in Nl))
             VF = hip.FMT_F16 if vol16 else hip.FMT_F32
-            psz = [(Pn * ldl[l] + 1) // 2 if vol16 else Pn * ldl[l] for l in range(L)]     # floats per level buffer
+            # row stride of a level: whole 128-byte lines, an ODD number of them - the transposed second output of the
+            # level-0 GEMM walks down a column, and at an even multiple (32640 floats = 255 x 512 bytes at 1080p) its
+            # stores queue on half the memory channels: 1989 us per launch against 1652 (tools/exp/volume_gemm_shapes.py)
+            unit = 64 if vol16 else 32
+            ldl = [(s + unit - 1) // unit * unit for s in Nl]
+            ldl = [n if (n // unit) % 2 else n + unit for n in ldl]
+            psz = [(Pv * ldl[l] + 1) // 2 if vol16 else Pv * ldl[l] for l in range(L)]     # floats per level buffer
             keys = None
             if frame_keys is not None:   # geometry and arithmetic are part of a cached frame's identity
                 keys = [(k, H, W, L, self._plan_key(), self._packed_serial) for k in frame_keys]
 
             # K1 + K2: feature maps and pooled target pyramids, per frame (cached across windows)
-            feats = self._frame_features(src, list(range(N)), keys, H, W, P, dev, L, hl, wl, Sl)
+            feats = self._frame_features(src, list(range(N)), keys, H, W, P, dev, L, hl, wl, Sl, vt=VT)
 
             # K3/K4 correlation pyramids, one per problem (query frame -> target frame): level l is one
             # GEMM of the query frame's features against the 2^l-pooled features of the target frame.
@@ -679,7 +710,7 @@ class MOFNetHIP(_Holder):
                         # (a backward problem's level 0 computed directly uses VFML_CONV_SWAP_CROSS, the addition
                         # order of a transposed forward volume: both routes give the same bits)
                         rk = ("p", keys[tgt], keys[c]) if pk is not None else None
-                        gemm_form = AF == hip.FMT_S16 and Pn % 4 == 0 and Sl[0] >= 1024
+                        gemm_form = AF == hip.FMT_S16 and Pv % 4 == 0 and Nl[0] >= 1024
                         dual = (rk is not None and d == "f" and gemm_form and ("p", rk) not in self._feat_cache
                                 and not os.environ.get("VFML_NO_DUAL"))      # (A/B switch; results are identical)
                         rev = None
@@ -689,14 +720,14 @@ class MOFNetHIP(_Holder):
                         cnm = self._nm("corr") if self._split() else 3
                         for l in range(L):
                             # (one MFMA per product is symmetric in its operands: no swapped cross terms to order)
-                            hip.conv2d(feats[c][0], D, D, 1, 1, Pn, feats[tgt][1][l], None, Sl[l], 1, 1, pyr[l],
+                            hip.conv2d(feats[c][0], D, D, 1, 1, Pv, feats[tgt][1][l], None, Nl[l], 1, 1, pyr[l],
                                        ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF,
                                        swap_cross=(d == "b" and l == 0 and gemm_form and cnm == 3),
                                        out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0,
                                        mfma=cnm)
                         if dual:
                             for l in range(1, L):
-                                hip.conv2d(feats[tgt][0], D, D, 1, 1, Pn, feats[c][1][l], None, Sl[l], 1, 1, rev[l],
+                                hip.conv2d(feats[tgt][0], D, D, 1, 1, Pv, feats[c][1][l], None, Nl[l], 1, 1, rev[l],
                                            ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF, mfma=cnm)
                     pyrs[d].append(pyr)
 
@@ -756,9 +787,9 @@ class MOFNetHIP(_Holder):
                     nm = min(M, left + 2) if pick_only and not self.tri_frame else M
                     # K5
                     hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF,
-                                    table=tab_f, nmaps=nm, vol_fmt=VF)
+                                    table=tab_f, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
                     hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF,
-                                    table=tab_b, nmaps=nm, vol_fmt=VF)
+                                    table=tab_b, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
                     # motion encoder
                     wgt, b = P[f"{ub}.encoder.convc1"]
                     hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
