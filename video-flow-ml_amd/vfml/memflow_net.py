@@ -196,19 +196,24 @@ class MemFlowNetHIP(MOFNetHIP):
                 hl.append(hl[-1] // 2)
                 wl.append(wl[-1] // 2)
             Sl = [hl[l] * wl[l] for l in range(L)]
-            ldl = [(s + 31) // 32 * 32 for s in Sl]
+            # volumes in tiles under tile-ordered rows, row strides an odd number of 128-byte lines (network.py _tile / _run)
+            VT = self._tile()
+            Nl = [VT.count(hl[l], wl[l]) for l in range(L)] if VT is not None else Sl
+            Pv, TILE = Nl[0], (VT.code if VT is not None else 0)
+            ldl = [(s + 31) // 32 * 32 for s in Nl]
+            ldl = [n if (n // 32) % 2 else n + 32 for n in ldl]
             keys = None
             if frame_keys is not None:
                 if len(frame_keys) != B + 1:
                     raise ValueError("frame_keys must hold one id per frame")
-                keys = [("memflow", k, H, W, L, self._precision(), self._packed_serial) for k in frame_keys]
-            feats = self._frame_features(src, list(range(B + 1)), keys, H, W, P, dev, L, hl, wl, Sl)
+                keys = [("memflow", k, H, W, L, self._precision(), TILE, self._packed_serial) for k in frame_keys]
+            feats = self._frame_features(src, list(range(B + 1)), keys, H, W, P, dev, L, hl, wl, Sl, vt=VT)
             ctx = self._frame_context_plain(src, B, H, W, P, dev, Pn, AF)       # cnet on the B previous frames
             pyrs = []
             for k in range(B):       # pair k: queries = frame k, targets = frame k+1
-                pyr = [self._buf(f"mpyr{k}_{l}", Pn * ldl[l], dev) for l in range(L)]
+                pyr = [self._buf(f"mpyr{k}_{l}", Pv * ldl[l], dev) for l in range(L)]
                 for l in range(L):
-                    hip.conv2d(feats[k][0], D, D, 1, 1, Pn, feats[k + 1][1][l], None, Sl[l], 1, 1, pyr[l], ldl[l],
+                    hip.conv2d(feats[k][0], D, D, 1, 1, Pv, feats[k + 1][1][l], None, Nl[l], 1, 1, pyr[l], ldl[l],
                                out_scale=1.0 / float(D) ** 0.5 / self.FMAP_ROW_SCALE, in_fmt=AF)   # query rows carry x16
                 pyrs.append(pyr)
 
@@ -278,7 +283,7 @@ class MemFlowNetHIP(MOFNetHIP):
             hip.coords_update(coords1, None, B, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124,
                               fmt_b=AF)
             for it in range(cfg.decoder_depth):
-                hip.corr_lookup(pyrs, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, cor_p, out_fmt=AF)
+                hip.corr_lookup(pyrs, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, cor_p, out_fmt=AF, vol_tile=TILE)
                 wgt, b = P[f"{ub}.encoder.convc1"]
                 hip.conv2d(corr, cor_p, cor_p, B, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
                            in_fmt=AF, out_fmt=AF)
