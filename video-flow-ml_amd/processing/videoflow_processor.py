@@ -215,9 +215,11 @@ class VideoFlowProcessor:
             flows, _ = model.forward_u8(win, return_lowres=False, frame_keys=keys, pick_only=self.PICK_ONLY)
             # the frame after this one is what a job asks for next: its window's new frame goes through the encoders
             # now, on a side stream beside this field's update iterations (vfml/network.py prefetch_frames)
-            # (whole frames only: a tiled job visits the other tiles of THIS frame next, and by the time it is back at this
-            # tile the engine's per-frame cache has turned over)
-            if tile is None and frame_idx + 1 < clip.shape[0] and hasattr(model, "prefetch_frames"):
+            # (whole frames, or a tile when the caller walks a tile's frames before the next tile - vfml/runner.py sets
+            # tiles_in_frame_order; the reference's own per-frame tile loop visits the other tiles of THIS frame next, and by
+            # the time it is back at this tile the engine's per-frame cache has turned over)
+            if ((tile is None or getattr(self, "tiles_in_frame_order", False)) and frame_idx + 1 < clip.shape[0]
+                    and hasattr(model, "prefetch_frames")):
                 nxt = self.window_indices(clip.shape[0], frame_idx + 1)
                 # (consecutive frames only: such a window is a VIEW of the clip - a gathered one would be produced on this
                 # stream, behind the iterations the prefetch is meant to run beside)

@@ -237,6 +237,9 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
         else:
             for j, (f, t) in enumerate(part):
                 feed(f)
+                # (items are tile-major: the call after this one is the NEXT FRAME of the same tile - what the processor's
+                # encoder prefetch assumes for whole frames holds for tiles too)
+                proc.tiles_in_frame_order = not whole
                 flow = proc.compute_optical_flow_resident(clip, f, tile=tiles[t])
                 sbuf[j, :flow.numel()].copy_(flow.reshape(-1))
 
