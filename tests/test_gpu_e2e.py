@@ -292,6 +292,36 @@ def test_prefetched_encoders_give_the_same_fields(gpu, monkeypatch):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_flow_half_of_the_motion_encoder_on_a_second_stream(gpu, monkeypatch, graph):
+    """VFML_FLOW_BRANCH=1: the flow half of the motion encoder (flow -> convf1 -> convf2) runs on a second stream beside the
+    lookups of the same iteration, joined before the convolution that reads both halves - eagerly and as two branches of the
+    captured graph.  Same kernels, same inputs: 1080p fields bit-identical to the one-stream engine."""
+    import contextlib
+    import io
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.synth import synthetic_clip
+    net, _ = _pair()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=5)
+    proc.core.model = net
+    clip = proc.upload_clip(synthetic_clip(9, 1080, 1920))
+    order = [2, 3, 4, 5, 6]
+    monkeypatch.setenv("VFML_GRAPH", graph)
+    monkeypatch.setenv("VFML_FLOW_BRANCH", "0")
+    net.clear_feature_cache()
+    one = [proc.compute_optical_flow_resident(clip, i).clone() for i in order]
+    monkeypatch.setenv("VFML_FLOW_BRANCH", "1")
+    for rep in range(2):
+        net.clear_feature_cache()
+        two = [proc.compute_optical_flow_resident(clip, i).clone() for i in order]
+        torch.cuda.synchronize()
+        for i, a, b in zip(order, one, two):
+            assert torch.equal(a, b), f"field {i} (pass {rep}): {int((a != b).sum())} values differ, max {float((a - b).abs().max()):.3g} px"
+    net.clear_feature_cache()
+    torch.cuda.empty_cache()
+
+
 def test_bof_fields_batched_equal_fields_one_by_one(gpu):
     """`--vf-architecture bof`, seq 9: consecutive interior fields go through the tri-frame network four at a
     time (tri_batch); clip-edge fields, whose centre triples repeat frames, one by one.  Both orders of

@@ -79,6 +79,7 @@ class MOFNetHIP(_Holder):
         self._packed_serial = 0
         self._ws = {}
         self._graphs = {}
+        self._side2 = {}      # per device: the stream of the flow half of the motion encoder (_run body)
         self._pyr_free = []
         self._side = {}                # per device: the stream the next window's encoders run on (prefetch_frames)
         self._prefetch_done = None     # event: the last prefetch's launches
@@ -777,6 +778,11 @@ class MOFNetHIP(_Holder):
                                   fmt_b=AF)
                 ub = "update_block"
                 mf = self._nm if self._split() else (lambda layer: 3)     # MFMAs per product of a layer (cfg.precision)
+                branch = None
+                if os.environ.get("VFML_FLOW_BRANCH", "0") == "1" and self._split():
+                    branch = self._side2.get(dev)
+                    if branch is None:
+                        branch = self._side2[dev] = torch.cuda.Stream(device=dev)
                 for it in range(cfg.decoder_depth):
                     # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
                     # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
@@ -785,6 +791,32 @@ class MOFNetHIP(_Holder):
                     left = cfg.decoder_depth - 1 - it
                     ng = min(M, left + 1) if pick_only and not self.tri_frame else M
                     nm = min(M, left + 2) if pick_only and not self.tri_frame else M
+                    # The flow half of the motion encoder (flow -> convf1 -> convf2 -> channels 192..255 of `cf`) needs
+                    # nothing of the correlation half (lookups -> convc1 -> convc2 -> channels 0..191): on a second stream
+                    # its small MFMA-bound convolutions run BESIDE the HBM-bound lookups (a fork / join of two events; inside
+                    # a captured graph, two branches).  Same kernels on the same inputs: bit-identical fields.
+                    def flow_half(nm=nm):
+                        wgt, b = P[f"{ub}.encoder.convf1"]
+                        if self._rows7:
+                            hip.flow_rows7(flow4, nm, h, w, frows)
+                            hip.conv2d(frows, 32, 32, nm, h, w, wgt, b, 128, 7, 1, f1, 128, pad_h=3, epilogue=hip.EPI_RELU,
+                                       in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
+                        else:
+                            hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
+                                       out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
+                        wgt, b = P[f"{ub}.encoder.convf2"]
+                        hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
+                                   epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf2"))
+
+                    join = None
+                    if branch is not None:
+                        fork = torch.cuda.Event()
+                        fork.record()                      # (flow4 of the previous iteration is complete on this stream)
+                        with torch.cuda.stream(branch):
+                            branch.wait_event(fork)
+                            flow_half()
+                            join = torch.cuda.Event()
+                            join.record()
                     # K5
                     hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF,
                                     table=tab_f, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
@@ -797,17 +829,10 @@ class MOFNetHIP(_Holder):
                     wgt, b = P[f"{ub}.encoder.convc2"]
                     hip.conv2d(c1, 256, 256, nm, h, w, wgt, b, 192, 3, 3, cf, 256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
                                in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convc2"))
-                    wgt, b = P[f"{ub}.encoder.convf1"]
-                    if self._rows7:
-                        hip.flow_rows7(flow4, nm, h, w, frows)
-                        hip.conv2d(frows, 32, 32, nm, h, w, wgt, b, 128, 7, 1, f1, 128, pad_h=3, epilogue=hip.EPI_RELU,
-                                   in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
+                    if join is None:
+                        flow_half()
                     else:
-                        hip.conv2d(flow4, 4, 4, nm, h, w, wgt, b, 128, 7, 7, f1, 128, pad_h=3, pad_w=3, epilogue=hip.EPI_RELU,
-                                   out_fmt=AF, mfma=mf(f"{ub}.encoder.convf1"))
-                    wgt, b = P[f"{ub}.encoder.convf2"]
-                    hip.conv2d(f1, 128, 128, nm, h, w, wgt, b, 64, 3, 3, cf, 256, out_off=192, pad_h=1, pad_w=1,
-                               epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.convf2"))
+                        torch.cuda.current_stream(dev).wait_event(join)
                     wgt, b = P[f"{ub}.encoder.conv"]
                     hip.conv2d(cf, 256, 256, nm, h, w, wgt, b, 124, 3, 3, G, GLD, out_off=MF, pad_h=1, pad_w=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.encoder.conv"))
@@ -870,7 +895,7 @@ class MOFNetHIP(_Holder):
                                                 up_fixed, out_off=(d * M + c) * H * W * 2)
 
             gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(), vol16,
-                    self._packed_serial, str(dev))
+                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"))
             self._pre_body = torch.cuda.Event()
             self._pre_body.record(torch.cuda.current_stream(dev))      # (what a prefetch of the next window waits for)
             self._run_body(body, gkey, dev)
