@@ -81,6 +81,7 @@ class MOFNetHIP(_Holder):
         self._graphs = {}
         self._side2 = {}      # per device: the stream of the flow half of the motion encoder (_run body)
         self._pyr_free = []
+        self._pyr_busy = set()    # cache keys of the pyramids the field in flight reads (a prefetch must not recycle them)
         self._side = {}                # per device: the stream the next window's encoders run on (prefetch_frames)
         self._prefetch_done = None     # event: the last prefetch's launches
         self._pre_body = None          # event: the last field's inputs are ready, its iterations not yet queued
@@ -461,15 +462,16 @@ class MOFNetHIP(_Holder):
             return
         L, dev = cfg.corr_levels, frames.device
         h, w = H // 8, W // 8
-        hl, wl = [h], [w]
-        for l in range(1, L):
-            hl.append(hl[-1] // 2)
-            wl.append(wl[-1] // 2)
-        Sl = [hl[l] * wl[l] for l in range(L)]
+        AF = hip.FMT_S16 if self._split() else hip.FMT_F32
+        geo = self._volume_geometry(H, W, L, AF)
+        hl, wl, Sl = geo.hl, geo.wl, geo.Sl
         keys = [(k, H, W, L, self._plan_key(), self._packed_serial) for k in frame_keys]
         need_f = [j for j in range(N) if ("f", keys[j]) not in self._feat_cache]
         need_c = [j for j in range(1, N - 1) if ("c", keys[j]) not in self._feat_cache]
-        if not need_f and not need_c:
+        # ... and the window's new correlation pyramids: HBM-write-bound GEMMs beside MFMA-bound iterations
+        need_p = self._prefetch_pyramids() and any(("p", keys[c], keys[t]) not in self._feat_cache
+                                                   for c in range(1, N - 1) for t in (c + 1, c - 1))
+        if not need_f and not need_c and not need_p:
             return
         main = torch.cuda.current_stream(dev)
         side = self._side.get(dev)
@@ -487,10 +489,15 @@ class MOFNetHIP(_Holder):
             need_c = []
         with torch.cuda.stream(side):
             new = []
-            if need_f:
-                new += list(self._frame_features(frames, need_f, keys, H, W, P, dev, L, hl, wl, Sl, vt=self._tile()).values())
+            feats = None
+            if need_f or need_p:
+                feats = self._frame_features(frames, list(range(N)) if need_p else need_f, keys, H, W, P, dev, L, hl, wl, Sl,
+                                             vt=geo.VT)
+                new += list(feats.values())
             if need_c:
                 new += list(self._frame_context(frames, need_c, keys, H, W, P, dev, h * w).values())
+            if need_p:
+                new.append(self._window_pyramids(feats, keys, N, geo, dev, protect=self._pyr_busy))
             done = torch.cuda.Event()
             done.record(side)
         # the cached tensors were allocated on the side stream and will be read (and one day freed) under the main one
@@ -509,13 +516,15 @@ class MOFNetHIP(_Holder):
         walk(new)
         self._prefetch_done = done
 
-    def _pyramid_buffers(self, sizes, dev, limit):
+    def _pyramid_buffers(self, sizes, dev, limit, protect=()):
         """Level buffers for a new correlation pyramid (5.6 GB at 1080p).  When the pyramid cache is at its
         limit the least recently used pyramid is retired FIRST and its buffers are handed to the new one:
         in the steady state of a sliding job no field allocates (a 5.6 GB hipMalloc costs up to 150 ms, and
         retiring only after the new allocation made the third field of every job pay for one)."""
         while sum(1 for k in self._feat_cache if k[0] == "p") >= limit:
-            oldest = next(k for k in self._feat_cache if k[0] == "p")
+            oldest = next((k for k in self._feat_cache if k[0] == "p" and k not in protect), None)
+            if oldest is None:        # everything cached is being read on another stream: a fresh allocation it is
+                break
             self._pyr_free.append(self._feat_cache.pop(oldest))
         for i, bufs in enumerate(self._pyr_free):
             if [b.numel() for b in bufs] == sizes and bufs[0].device == dev:
@@ -534,6 +543,98 @@ class MOFNetHIP(_Holder):
         while sum(1 for k in self._feat_cache if k[0] == kind) > (limit or self.FEATURE_CACHE_FRAMES):
             oldest = next(k for k in self._feat_cache if k[0] == kind)
             del self._feat_cache[oldest]
+
+    def _volume_geometry(self, H, W, L, AF):
+        """Shapes of a window's correlation volumes: level sizes, the tile layout, element format, row strides, buffer sizes."""
+        import types
+        cfg = self.cfg
+        h, w = H // 8, W // 8
+        hl, wl = [h], [w]
+        for l in range(1, L):
+            hl.append(hl[-1] // 2)
+            wl.append(wl[-1] // 2)
+        Sl = [hl[l] * wl[l] for l in range(L)]
+        # volume geometry: Nl columns per level, Pv rows - the pixels, or the whole tiles of a tiled volume (_tile)
+        VT = self._tile()
+        Nl = [VT.count(hl[l], wl[l]) for l in range(L)] if VT is not None else Sl
+        Pv = Nl[0]
+        TILE = VT.code if VT is not None else 0
+        # cfg.corr_volume 'f16': the pyramids as one f16 per value, written by the GEMM form (which needs every level's
+        # width a multiple of 4 and split-row query features) - other geometries keep f32 volumes
+        vol16 = (getattr(cfg, "corr_volume", "f32") == "f16" and AF == hip.FMT_S16 and Pv % 4 == 0
+                 and all(s % 4 == 0 for s in Nl))
+        VF = hip.FMT_F16 if vol16 else hip.FMT_F32
+        # row stride of a level: whole 128-byte lines, an ODD number of them - the transposed second output of the
+        # level-0 GEMM walks down a column, and at an even multiple (32640 floats = 255 x 512 bytes at 1080p) its
+        # stores queue on half the memory channels: 1989 us per launch against 1652 (tools/exp/volume_gemm_shapes.py)
+        unit = 64 if vol16 else 32
+        ldl = [(s + unit - 1) // unit * unit for s in Nl]
+        ldl = [n if (n // unit) % 2 else n + unit for n in ldl]
+        psz = [(Pv * ldl[l] + 1) // 2 if vol16 else Pv * ldl[l] for l in range(L)]     # floats per level buffer
+        return types.SimpleNamespace(L=L, AF=AF, hl=hl, wl=wl, Sl=Sl, VT=VT, Nl=Nl, Pv=Pv, TILE=TILE, vol16=vol16, VF=VF,
+                                     ldl=ldl, psz=psz)
+
+    def _prefetch_pyramids(self):
+        """VFML_PREFETCH_PYR=1: the next window's new correlation pyramids are built on the prefetch stream too.  Off: the
+        resident workgroups of the persistent volume GEMM take a workgroup slot of every CU from the iterations'
+        convolutions for as long as they run - 24.75 ms per field with it against 24.70 without (fields bit-identical)."""
+        return os.environ.get("VFML_PREFETCH", "1") != "0" and os.environ.get("VFML_PREFETCH_PYR", "0") == "1" and not self.tri_frame
+
+    def _window_pyramids(self, feats, keys, N, geo, dev, protect=()):
+        """K3/K4: the correlation pyramids of a window, one per problem (query frame -> target frame): level l is one GEMM of
+        the query frame's features against the 2^l-pooled features of the target frame.  A pyramid depends on its two frames
+        only, so with frame keys it is kept across windows: consecutive sliding windows share 2(N-3) of their 2(N-2)
+        problems.  Returns {"f": [...], "b": [...]} (per centre frame, a list of level buffers).
+        protect: cache keys of pyramids another stream is reading - their buffers are not recycled for new ones."""
+        D, L = self.cfg.feat_dim, geo.L
+        AF, VF, Nl, Pv, ldl, psz = geo.AF, geo.VF, geo.Nl, geo.Pv, geo.ldl, geo.psz
+        scale = 1.0 / float(D) ** 0.5
+        if AF == hip.FMT_S16:
+            scale /= self.FMAP_ROW_SCALE       # the split-row query features carry a factor 16
+        # (two more than a window and its reverse twin need when the next window's are built beside this one's iterations)
+        lim = 2 * (N - 2) + 2 + (2 if self._prefetch_pyramids() else 0)
+        pyrs = {"f": [], "b": []}
+        for c in range(1, N - 1):
+            for d, tgt in (("f", c + 1), ("b", c - 1)):
+                pk = ("p", keys[c], keys[tgt]) if keys is not None else None
+                pyr = self._cache_get("p", pk) if pk is not None else None
+                if pyr is None:
+                    if pk is None:    # uncached call: reuse one workspace set per problem slot
+                        pyr = [self._buf(f"pyr_{d}{c}_{l}", psz[l], dev) for l in range(L)]
+                    else:
+                        # (registered before it is filled: same stream, and the next allocation then sees
+                        # the right count and retires a stale pyramid instead of asking the allocator)
+                        pyr = self._pyramid_buffers(psz, dev, limit=lim, protect=protect)
+                        self._cache_put("p", pk, pyr, limit=lim)
+                    # Level 0 of the reverse problem (tgt -> c) is the transpose of this one's: when it is
+                    # going to be needed (tgt is, or next field becomes, a centre frame: the "f" problems of
+                    # a forward-sliding job) the same pass of MFMAs stores it too (vfml_conv_desc.out_t), and
+                    # only its three pooled levels are separate GEMMs.  In the steady state a field then
+                    # builds its two new pyramids with one 32400 x 32400 GEMM instead of two.
+                    # (a backward problem's level 0 computed directly uses VFML_CONV_SWAP_CROSS, the addition
+                    # order of a transposed forward volume: both routes give the same bits)
+                    rk = ("p", keys[tgt], keys[c]) if pk is not None else None
+                    gemm_form = AF == hip.FMT_S16 and Pv % 4 == 0 and Nl[0] >= 1024
+                    dual = (rk is not None and d == "f" and gemm_form and ("p", rk) not in self._feat_cache
+                            and not os.environ.get("VFML_NO_DUAL"))      # (A/B switch; results are identical)
+                    rev = None
+                    if dual:
+                        rev = self._pyramid_buffers(psz, dev, limit=lim, protect=protect)
+                        self._cache_put("p", rk, rev, limit=lim)
+                    cnm = self._nm("corr") if self._split() else 3
+                    for l in range(L):
+                        # (one MFMA per product is symmetric in its operands: no swapped cross terms to order)
+                        hip.conv2d(feats[c][0], D, D, 1, 1, Pv, feats[tgt][1][l], None, Nl[l], 1, 1, pyr[l],
+                                   ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF,
+                                   swap_cross=(d == "b" and l == 0 and gemm_form and cnm == 3),
+                                   out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0,
+                                   mfma=cnm)
+                    if dual:
+                        for l in range(1, L):
+                            hip.conv2d(feats[tgt][0], D, D, 1, 1, Pv, feats[c][1][l], None, Nl[l], 1, 1, rev[l],
+                                       ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF, mfma=cnm)
+                pyrs[d].append(pyr)
+        return pyrs
 
     def _frame_features(self, src, sel, keys, H, W, P, dev, L, hl, wl, Sl, vt=None):
         """Feature map + target pyramid of frames `sel` of the window.
@@ -653,28 +754,8 @@ class MOFNetHIP(_Holder):
         cor_p = cor_pad(cor, AF == hip.FMT_S16)   # per-direction channel block
 
         with torch.cuda.device(dev):
-            hl, wl = [h], [w]
-            for l in range(1, L):
-                hl.append(hl[-1] // 2)
-                wl.append(wl[-1] // 2)
-            Sl = [hl[l] * wl[l] for l in range(L)]
-            # volume geometry: Nl columns per level, Pv rows - the pixels, or the whole tiles of a tiled volume (_tile)
-            VT = self._tile()
-            Nl = [VT.count(hl[l], wl[l]) for l in range(L)] if VT is not None else Sl
-            Pv = Nl[0]
-            TILE = VT.code if VT is not None else 0
-            # cfg.corr_volume 'f16': the pyramids as one f16 per value, written by the GEMM form (which needs every level's
-            # width a multiple of 4 and split-row query features) - other geometries keep f32 volumes
-            vol16 = (getattr(cfg, "corr_volume", "f32") == "f16" and AF == hip.FMT_S16 and Pv % 4 == 0
-                     and all(s % 4 == 0 for s in Nl))
-            VF = hip.FMT_F16 if vol16 else hip.FMT_F32
-            # row stride of a level: whole 128-byte lines, an ODD number of them - the transposed second output of the
-            # level-0 GEMM walks down a column, and at an even multiple (32640 floats = 255 x 512 bytes at 1080p) its
-            # stores queue on half the memory channels: 1989 us per launch against 1652 (tools/exp/volume_gemm_shapes.py)
-            unit = 64 if vol16 else 32
-            ldl = [(s + unit - 1) // unit * unit for s in Nl]
-            ldl = [n if (n // unit) % 2 else n + unit for n in ldl]
-            psz = [(Pv * ldl[l] + 1) // 2 if vol16 else Pv * ldl[l] for l in range(L)]     # floats per level buffer
+            geo = self._volume_geometry(H, W, L, AF)
+            hl, wl, Sl, VT, TILE, vol16, VF, ldl = geo.hl, geo.wl, geo.Sl, geo.VT, geo.TILE, geo.vol16, geo.VF, geo.ldl
             keys = None
             if frame_keys is not None:   # geometry and arithmetic are part of a cached frame's identity
                 keys = [(k, H, W, L, self._plan_key(), self._packed_serial) for k in frame_keys]
@@ -682,55 +763,10 @@ class MOFNetHIP(_Holder):
             # K1 + K2: feature maps and pooled target pyramids, per frame (cached across windows)
             feats = self._frame_features(src, list(range(N)), keys, H, W, P, dev, L, hl, wl, Sl, vt=VT)
 
-            # K3/K4 correlation pyramids, one per problem (query frame -> target frame): level l is one
-            # GEMM of the query frame's features against the 2^l-pooled features of the target frame.
-            # A pyramid depends on its two frames only, so with frame keys it is kept across windows:
-            # consecutive sliding windows share 2(N-3) of their 2(N-2) problems.
-            scale = 1.0 / float(D) ** 0.5
-            if AF == hip.FMT_S16:
-                scale /= self.FMAP_ROW_SCALE       # the split-row query features carry a factor 16
-            pyrs = {"f": [], "b": []}
-            for c in range(1, N - 1):
-                for d, tgt in (("f", c + 1), ("b", c - 1)):
-                    pk = ("p", keys[c], keys[tgt]) if keys is not None else None
-                    pyr = self._cache_get("p", pk) if pk is not None else None
-                    if pyr is None:
-                        if pk is None:    # uncached call: reuse one workspace set per problem slot
-                            pyr = [self._buf(f"pyr_{d}{c}_{l}", psz[l], dev) for l in range(L)]
-                        else:
-                            # (registered before it is filled: same stream, and the next allocation then sees
-                            # the right count and retires a stale pyramid instead of asking the allocator)
-                            lim = 2 * (N - 2) + 2
-                            pyr = self._pyramid_buffers(psz, dev, limit=lim)
-                            self._cache_put("p", pk, pyr, limit=lim)
-                        # Level 0 of the reverse problem (tgt -> c) is the transpose of this one's: when it is
-                        # going to be needed (tgt is, or next field becomes, a centre frame: the "f" problems of
-                        # a forward-sliding job) the same pass of MFMAs stores it too (vfml_conv_desc.out_t), and
-                        # only its three pooled levels are separate GEMMs.  In the steady state a field then
-                        # builds its two new pyramids with one 32400 x 32400 GEMM instead of two.
-                        # (a backward problem's level 0 computed directly uses VFML_CONV_SWAP_CROSS, the addition
-                        # order of a transposed forward volume: both routes give the same bits)
-                        rk = ("p", keys[tgt], keys[c]) if pk is not None else None
-                        gemm_form = AF == hip.FMT_S16 and Pv % 4 == 0 and Nl[0] >= 1024
-                        dual = (rk is not None and d == "f" and gemm_form and ("p", rk) not in self._feat_cache
-                                and not os.environ.get("VFML_NO_DUAL"))      # (A/B switch; results are identical)
-                        rev = None
-                        if dual:
-                            rev = self._pyramid_buffers(psz, dev, limit=lim)
-                            self._cache_put("p", rk, rev, limit=lim)
-                        cnm = self._nm("corr") if self._split() else 3
-                        for l in range(L):
-                            # (one MFMA per product is symmetric in its operands: no swapped cross terms to order)
-                            hip.conv2d(feats[c][0], D, D, 1, 1, Pv, feats[tgt][1][l], None, Nl[l], 1, 1, pyr[l],
-                                       ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF,
-                                       swap_cross=(d == "b" and l == 0 and gemm_form and cnm == 3),
-                                       out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0,
-                                       mfma=cnm)
-                        if dual:
-                            for l in range(1, L):
-                                hip.conv2d(feats[tgt][0], D, D, 1, 1, Pv, feats[c][1][l], None, Nl[l], 1, 1, rev[l],
-                                           ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF, mfma=cnm)
-                    pyrs[d].append(pyr)
+            # K3/K4 correlation pyramids, one per problem (query frame -> target frame)
+            pyrs = self._window_pyramids(feats, keys, N, geo, dev)
+            self._pyr_busy = ({("p", keys[c], keys[t]) for c in range(1, N - 1) for t in (c + 1, c - 1)}
+                              if keys is not None else set())
 
             # Recurrent state, one row of GLD floats per cell:  [ z | r*h | h | inp | mf | mt ]
             # (one allocation, so that cat([r*h, x]) and cat([h, x]) are channel slices of it)
