@@ -5,6 +5,7 @@ Stands in for `configs.multiframes_sintel_submission.get_cfg` of the VideoFlow s
 :92-94 `decoder_depth / corr_levels / corr_radius` for --fast).  A plain mutable attribute bag,
 like yacs' CfgNode as the reference uses it.
 """
+import os
 
 
 class Cfg:
@@ -34,7 +35,14 @@ DEFAULT_MIXED_PLAN = {
     "update_block.encoder.convf2": 1,
     "update_block.mask.0": 1,
     "update_block.mask.2": 1,
+    # activations as plain f16, weights still hi + lo ("2a": two MFMAs per product): the first q gate and the temporal
+    # fusion, 3.1e-5 / 2.5e-5 px on their own - the weights' rounding is what costs, not the activations'
+    "update_block.gru.convq1.iter": "2a",
+    "update_block.tprop": "2a",
 }
+# (A/B switch: VFML_PLAN_EXCLUDE="layer,layer" takes entries out of the default plan - those layers run all three terms)
+for _k in filter(None, os.environ.get("VFML_PLAN_EXCLUDE", "").split(",")):
+    DEFAULT_MIXED_PLAN.pop(_k, None)
 
 
 def get_cfg():
