@@ -84,6 +84,7 @@ class MOFNetHIP(_Holder):
         self._pyr_busy = set()    # cache keys of the pyramids the field in flight reads (a prefetch must not recycle them)
         self._side = {}                # per device: the stream the next window's encoders run on (prefetch_frames)
         self._prefetch_done = None     # event: the last prefetch's launches
+        self._prefetch_dev = None
         self._pre_body = None          # event: the last field's inputs are ready, its iterations not yet queued
         import collections
         self._feat_cache = collections.OrderedDict()
@@ -102,6 +103,7 @@ class MOFNetHIP(_Holder):
                tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is not None and self._packed_key == key:
             return self._packed
+        self._join_prefetch()          # (a prefetch in flight reads the planes this call replaces)
         P, cblock_names, cb64_names = {}, set(), set()
         cout_packed = {}       # layers whose packed matrix has another row count than their bias
         rows7 = set()          # convf1 as a 7x1 convolution over the horizontal taps' rows
@@ -276,11 +278,21 @@ class MOFNetHIP(_Holder):
         if t is None or t.numel() != numel or t.device != device or t.dtype != dtype:
             if t is not None:
                 self._graphs.clear()       # captured launches hold this buffer's address
+                self._join_prefetch()      # (the encoders' workspaces are shared with a prefetch in flight)
             t = (torch.zeros if zero else torch.empty)(int(numel), device=device, dtype=dtype)
             self._ws[name] = t
         return t
 
+    def _join_prefetch(self):
+        """Order the current stream behind a prefetch in flight (prefetch_frames): it runs on a side stream over workspaces,
+        weights and cache entries that were allocated under this one - whatever frees or replaces any of them, or reads what
+        the prefetch produces, has to come after it."""
+        if self._prefetch_done is not None:
+            torch.cuda.current_stream(self._prefetch_dev).wait_event(self._prefetch_done)
+            self._prefetch_done = None
+
     def release_workspace(self):
+        self._join_prefetch()
         self._graphs.clear()
         self._ws.clear()
         self._feat_cache.clear()
@@ -438,6 +450,7 @@ class MOFNetHIP(_Holder):
     FMAP_ROW_SCALE = 16.0       # power of two: exact; undone by the correlation GEMM's out_scale
 
     def clear_feature_cache(self):
+        self._join_prefetch()
         self._feat_cache.clear()
         self._pyr_free = []
 
@@ -487,6 +500,7 @@ class MOFNetHIP(_Holder):
             need_f = []
         if "noc" in dbg:
             need_c = []
+        frames.record_stream(side)       # (a view of the caller's clip: its block must outlive the side stream's reads)
         with torch.cuda.stream(side):
             new = []
             feats = None
@@ -514,7 +528,7 @@ class MOFNetHIP(_Holder):
             elif hasattr(x, "planes") and isinstance(getattr(x, "planes"), torch.Tensor):
                 x.planes.record_stream(main)
         walk(new)
-        self._prefetch_done = done
+        self._prefetch_done, self._prefetch_dev = done, dev
 
     def _pyramid_buffers(self, sizes, dev, limit, protect=()):
         """Level buffers for a new correlation pyramid (5.6 GB at 1080p).  When the pyramid cache is at its
@@ -741,9 +755,7 @@ class MOFNetHIP(_Holder):
         if (h >> (L - 1)) < 2 or (w >> (L - 1)) < 2:
             raise ValueError(f"frame {H}x{W} too small for a {L}-level correlation pyramid")
         dev = src.device
-        if self._prefetch_done is not None:      # a prefetch shares the encoders' workspaces and fills the caches read below
-            torch.cuda.current_stream(dev).wait_event(self._prefetch_done)
-            self._prefetch_done = None
+        self._join_prefetch()      # a prefetch shares the encoders' workspaces and fills the caches read below
         M = N - 2
         Pn = h * w          # cells per map
         MP = M * Pn
