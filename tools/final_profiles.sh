@@ -19,11 +19,11 @@ step "bench bof720p";     timeout -k 10 300 python3 bench.py --workload bof720p 
 step "bench 4k tile";     timeout -k 10 300 python3 bench.py --workload mof4k-tile --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_4k.log 2>&1 && tail -1 $OUT/bench_4k.log > $OUT/${TAG}_mof4k_tile_bench.json || exit 1
 step "rocprofv3 stats (as shipped)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline > $OUT/prof.log 2>&1 || exit 1
-tail -1 $OUT/prof.log > $OUT/${TAG}_bench_profiled.json
+grep "^{\"metric\"" $OUT/prof.log | tail -1 > $OUT/${TAG}_bench_profiled.json
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_mixed_kernel_stats.csv
 step "rocprofv3 stats (prefetch off)"
 VFML_PREFETCH=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof0 -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline > $OUT/prof0.log 2>&1 || exit 1
-tail -1 $OUT/prof0.log > $OUT/${TAG}_bench_profiled_prefetch_off.json
+grep "^{\"metric\"" $OUT/prof0.log | tail -1 > $OUT/${TAG}_bench_profiled_prefetch_off.json
 cp $(find $OUT/prof0 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_mixed_prefetch_off_kernel_stats.csv
 step "pmc FETCH_SIZE"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_fetch.log 2>&1 || exit 1

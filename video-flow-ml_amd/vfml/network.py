@@ -283,6 +283,9 @@ class MOFNetHIP(_Holder):
             self._ws[name] = t
         return t
 
+    _prefetch_done = None      # (class defaults: engines that share this class's plumbing but never prefetch)
+    _prefetch_dev = None
+
     def _join_prefetch(self):
         """Order the current stream behind a prefetch in flight (prefetch_frames): it runs on a side stream over workspaces,
         weights and cache entries that were allocated under this one - whatever frees or replaces any of them, or reads what
