@@ -128,127 +128,154 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
   }
 }
 
-// The same lookup with the radius as a compile-time constant (4: default, 3: --fast): the patch / window
-// index arithmetic becomes multiplications by constants instead of integer divisions (the generic kernel
-// spends more issue slots on `e / psz`, `idx / side`, `c / (win*win)` than on its loads), and a lane
-// produces four consecutive output channels, stored as one 16-byte run (f32) or two 8-byte runs (split rows).
+// The bilinear mix with the four weight products already formed (the same products, the same chain: bit-identical to bilinear4).
+__device__ __forceinline__ float bilinear4w(float nw, float ne, float sw, float se, float w00, float w10, float w01, float w11) {
+  float v = ne * w10;
+  v = __builtin_fmaf(nw, w00, v);
+  v = __builtin_fmaf(sw, w01, v);
+  v = __builtin_fmaf(se, w11, v);
+  return v;
+}
+
+// What one wave of the fixed-radius kernel orders between its LDS writes and the reads other lanes make of them (LDS
+// operations of a wave execute in order; this keeps the compiler from moving them and waits for the counters).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The same lookup with the radius as a compile-time constant (4: default, 3: --fast), one wave per query, no workgroup
+// barrier.  The kernel is bound by the instructions it issues as much as by the lines it gathers (round 2: ~710 VALU
+// instructions per query = 1.5 us of a SIMD, 95 queries per SIMD per launch at 1080p), so every phase is laid out for few
+// instructions:
+//   gather    level by level (compile-time level: shapes, row pointer and window origin sit in scalar registers, the
+//             power-of-two scale is a constant, no per-lane selects), a level's (2R+2)^2 texels in two passes of the wave;
+//             every load unconditional on a clamped address, the value zeroed afterwards if the texel is outside
+//   mix       lane (level, x offset) walks its column of 2R+1 samples downwards: the lower texel pair of one sample is the
+//             upper pair of the next (one ds_read2 and four multiply-adds per sample, no index arithmetic)
+//   store     the samples go through LDS so that a lane owns one 8-channel unit: 32 bytes of split row (or two quads of f32)
 template <int R, bool OUT16, bool VOL16 = false>
 __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(const LookupArgs a) {
   constexpr int SIDE = 2 * R + 2, PSZ = SIDE * SIDE, WIN = 2 * R + 1, WW = WIN * WIN;
+  constexpr int NOUTPAD = (FIXED_LEVELS * WW + 7) & ~7;
+  static_assert(PSZ <= 128 && FIXED_LEVELS * WIN <= 64 && NOUTPAD / 8 <= 64, "one wave: at most two gather passes per level");
   __shared__ float patch[LOOKUP_WAVES][FIXED_LEVELS][PSZ];
-  __shared__ float frac[LOOKUP_WAVES][FIXED_LEVELS][2];
+  __shared__ __attribute__((aligned(16))) float outs[LOOKUP_WAVES][NOUTPAD];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int q = blockIdx.x * LOOKUP_WAVES + wv;
-  const bool live = q < a.nq;
-  // the wave's query is uniform: pyramid pointers and level shapes come through scalar registers and are picked
-  // per lane with selects (a per-lane index into the kernel arguments would be a dependent memory load)
-  const int map = __builtin_amdgcn_readfirstlane(live ? q / a.q_per_map : 0);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.x * LOOKUP_WAVES + wv;       // the wave's query: everything derived from it is scalar
+  if (q >= a.nq) return;
+  // (integer division runs on the vector unit: readfirstlane tells the compiler its result is still one value per wave)
+  const int map = __builtin_amdgcn_readfirstlane(q / a.q_per_map);
   const int qq = q - map * a.q_per_map;
-  if (live) {
-    const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
-    const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
-    const int total = a.levels * PSZ;
-    constexpr int ES = VOL16 ? 2 : 4;        // bytes per texel of the volume
-    const int qrow = (a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq;
-    const char* lp[FIXED_LEVELS];
-    int lw[FIXED_LEVELS], lh[FIXED_LEVELS];
+  const int qrow = __builtin_amdgcn_readfirstlane((a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq);
+  const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
+  const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
+  constexpr int ES = VOL16 ? 2 : 4;        // bytes per texel of the volume
+  // the two passes of a level: window cells lane and lane + 64 (the second pass: cells 64 .. PSZ-1)
+  const int pyA = lane / SIDE, pxA = lane - pyA * SIDE;
+  const int pyB = (lane + 64) / SIDE, pxB = (lane + 64) - pyB * SIDE;
+  const bool inB = lane + 64 < PSZ;
+  // Row pointers of all levels first (a device table is read here), then STRAIGHT-LINE code for the gathers: behind a
+  // branch - even a uniform `l < levels` - hipcc waits for a level's texels before it asks for the next level's.  A level the
+  // call does not have reads level 0's first texel and drops it.
+  const float* pl[FIXED_LEVELS];
+  if (a.table) {
 #pragma unroll
-    for (int l = 0; l < FIXED_LEVELS; ++l) {
-      lp[l] = l < a.levels ? reinterpret_cast<const char*>(a.table ? a.table[map * a.levels + l] : a.pyr[map][l]) + (int64_t)qrow * a.ld[l] * ES
-                           : nullptr;
-      lw[l] = a.wl[l];
-      lh[l] = a.hl[l];
-    }
-    // all texels of the query are requested before the first one is used: NLOAD independent loads in flight per
-    // lane.  The loads are UNCONDITIONAL (window cells outside the level read its clamped edge texel and are zeroed
-    // by a select afterwards): behind a per-lane bounds branch hipcc waits vmcnt(0) at every join, i.e. it pays the
-    // HBM latency NLOAD times.  They are also explicitly GLOBAL loads: a pointer picked among several by selects
-    // loses its address space and becomes flat_load, which returned wrong texels for a few dozen queries per launch
-    // whenever another of this library's MFMA kernels ran on a second stream (profiles/r02_kernel_anatomy.md 7).
-    constexpr int NLOAD = (FIXED_LEVELS * PSZ + 63) / 64;
-    float val[NLOAD];
-    bool ok[NLOAD];
+    for (int l = 0; l < FIXED_LEVELS; ++l) pl[l] = a.table[map * a.levels + (l < a.levels ? l : 0)];
+  } else {
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      const int e = lane + 64 * it;
-      const bool in = e < total;
-      const int l = in ? e / PSZ : 0;
-      const int idx = e - l * PSZ;
-      const int py = idx / SIDE, px = idx - py * SIDE;
-      const float inv = 1.0f / (float)(1 << l);
-      const float x = cx * inv, y = cy * inv;  // exact: power-of-two scale
-      const int x0 = (int)fminf(fmaxf(floorf(x), -65536.f), 65536.f) - R;
-      const int y0 = (int)fminf(fmaxf(floorf(y), -65536.f), 65536.f) - R;
+    for (int l = 0; l < FIXED_LEVELS; ++l) pl[l] = a.pyr[map][l < a.levels ? l : 0];
+  }
+  float va[FIXED_LEVELS], vb[FIXED_LEVELS];
+  bool oka[FIXED_LEVELS], okb[FIXED_LEVELS];
+#pragma unroll
+  for (int l = 0; l < FIXED_LEVELS; ++l) {
+    const bool have = l < a.levels;
+    const int ll = have ? l : 0;
+    const char* base = reinterpret_cast<const char*>(pl[l]) + (int64_t)qrow * a.ld[ll] * ES;
+    const int wl = a.wl[ll], hl = a.hl[ll];
+    const float inv = __builtin_bit_cast(float, (127 - l) << 23);      // 2^-l, exactly what 1.0f / (1 << l) is
+    const float x = cx * inv, y = cy * inv;                            // exact: power-of-two scale
+    const int x0 = (int)fminf(fmaxf(floorf(x), -65536.f), 65536.f) - R;   // (clamped before the conversion: wild coordinates)
+    const int y0 = (int)fminf(fmaxf(floorf(y), -65536.f), 65536.f) - R;
+    auto texel = [&](int px, int py, bool in, float& out, bool& ok) {
       const int xx = x0 + px, yy = y0 + py;
-      const char* base = l == 0 ? lp[0] : (l == 1 ? lp[1] : (l == 2 ? lp[2] : lp[3]));
-      const int wl = l == 0 ? lw[0] : (l == 1 ? lw[1] : (l == 2 ? lw[2] : lw[3]));
-      const int hl = l == 0 ? lh[0] : (l == 1 ? lh[1] : (l == 2 ? lh[2] : lh[3]));
-      ok[it] = in && xx >= 0 && xx < wl && yy >= 0 && yy < hl;
+      ok = have && in && xx >= 0 && xx < wl && yy >= 0 && yy < hl;
       const int at = tiled_at(min(max(yy, 0), hl - 1), min(max(xx, 0), wl - 1), wl, a.tws, a.ths);
-      if constexpr (VOL16) val[it] = (float)((const __attribute__((address_space(1))) _Float16*)base)[at];
-      else val[it] = ((const __attribute__((address_space(1))) float*)base)[at];
-    }
+      // (explicitly GLOBAL: a pointer that went through selects or a table loses its address space and becomes flat_load)
+      if constexpr (VOL16) out = (float)((const __attribute__((address_space(1))) _Float16*)base)[at];
+      else out = ((const __attribute__((address_space(1))) float*)base)[at];          // (zeroed below, once every load is on its way)
+    };
+    texel(pxA, pyA, true, va[l], oka[l]);
+    if constexpr (PSZ > 64) texel(pxB, pyB, inB, vb[l], okb[l]);
+    else { vb[l] = 0.f; okb[l] = false; }
+  }
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) val[it] = ok[it] ? val[it] : 0.f;
+  for (int l = 0; l < FIXED_LEVELS; ++l) {
+    va[l] = oka[l] ? va[l] : 0.f;
+    vb[l] = okb[l] ? vb[l] : 0.f;
+  }
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      const int e = lane + 64 * it;
-      if (e < total) (&patch[wv][0][0])[e] = val[it];
-    }
-    if (lane < a.levels) {
-      const float inv = 1.0f / (float)(1 << lane);
-      const float x = cx * inv, y = cy * inv;
-      frac[wv][lane][0] = x - floorf(x);
-      frac[wv][lane][1] = y - floorf(y);
+  for (int l = 0; l < FIXED_LEVELS; ++l) {
+    if (l < a.levels) {
+      if (PSZ > 64 || lane < PSZ) patch[wv][l][lane] = va[l];
+      if constexpr (PSZ > 64) if (inB) patch[wv][l][lane + 64] = vb[l];
     }
   }
-  __syncthreads();
-  if (!live) return;
   const int nout = a.levels * WW;
-  float* o = a.out + (int64_t)q * a.ld_out;
-  const int nquads = OUT16 ? ((nout + 7) & ~7) / 4 : (nout + 3) / 4;   // split rows: zero-fill up to a whole unit
-  for (int c4 = lane; c4 < nquads; c4 += 64) {
-    float v[4];
+  const int nunits = (nout + 7) >> 3;
+  if (lane >= 56 && nout + (lane - 56) < nunits * 8) outs[wv][nout + (lane - 56)] = 0.f;   // the zero channels that fill the last unit
+  wave_lds_sync();
+  if (lane < a.levels * WIN) {
+    const int l = lane / WIN, i = lane - l * WIN;          // i: x offset index; the lane walks j, the y offset index
+    const float inv = __builtin_bit_cast(float, (127 - l) << 23);
+    const float x = cx * inv, y = cy * inv;
+    const float fx = x - floorf(x), fy = y - floorf(y);
+    const float wx0 = 1.f - fx, wy0 = 1.f - fy;
+    const float w00 = wx0 * wy0, w10 = fx * wy0, w01 = wx0 * fy, w11 = fx * fy;
+    const float* p = &patch[wv][l][i];
+    float* o = &outs[wv][l * WW + i * WIN];
+    float nw = p[0], ne = p[1];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c4 * 4 + k;
-      v[k] = 0.f;
-      if (c < nout) {
-        const int l = c / WW;
-        const int rem = c - l * WW;
-        const int i = rem / WIN, j = rem - i * WIN;  // i: x offset index, j: y offset index
-        const float fx = frac[wv][l][0], fy = frac[wv][l][1];
-        const float* p = &patch[wv][l][j * SIDE + i];
-        const float wx0 = 1.f - fx, wy0 = 1.f - fy;
-        // (the same fused chain as the generic kernel: results are bit-identical)
-#ifdef VFML_LOOKUP_OLD_ARITH
-        v[k] = p[0] * (wx0 * wy0) + p[1] * (fx * wy0) + p[SIDE] * (wx0 * fy) + p[SIDE + 1] * (fx * fy);
-#else
-        v[k] = bilinear4(p[0], p[1], p[SIDE], p[SIDE + 1], wx0, fx, wy0, fy);
-#endif
-      }
+    for (int j = 0; j < WIN; ++j) {
+      const float sw = p[(j + 1) * SIDE], se = p[(j + 1) * SIDE + 1];
+      o[j] = bilinear4w(nw, ne, sw, se, w00, w10, w01, w11);
+      nw = sw; ne = se;
     }
+  }
+  wave_lds_sync();
+  if (lane < nunits) {
+    float* o = a.out + (int64_t)q * a.ld_out + lane * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&outs[wv][lane * 8]);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&outs[wv][lane * 8 + 4]);
     if (OUT16) {
-      vfml_h16x2 h0, h1, l0, l1;
-      vfml_split2(v[0], v[1], h0, l0);
-      vfml_split2(v[2], v[3], h1, l1);
-      // quad c4 of unit c4/2: hi halves at byte 8*(c4&1) of the 32-byte unit, lo halves 16 bytes further
-      char* u = reinterpret_cast<char*>(o + (c4 >> 1) * 8) + 8 * (c4 & 1);
-      uint2 hv, lv;
+      // one unit of the split row: eight hi halves, then the eight lo halves
+      vfml_h16x2 h0, h1, h2, h3, l0, l1, l2, l3;
+      vfml_split2(v0[0], v0[1], h0, l0);
+      vfml_split2(v0[2], v0[3], h1, l1);
+      vfml_split2(v1[0], v1[1], h2, l2);
+      vfml_split2(v1[2], v1[3], h3, l3);
+      uint4 hv, lv;
       hv.x = __builtin_bit_cast(unsigned, h0); hv.y = __builtin_bit_cast(unsigned, h1);
+      hv.z = __builtin_bit_cast(unsigned, h2); hv.w = __builtin_bit_cast(unsigned, h3);
       lv.x = __builtin_bit_cast(unsigned, l0); lv.y = __builtin_bit_cast(unsigned, l1);
-      *reinterpret_cast<uint2*>(u) = hv;
-      *reinterpret_cast<uint2*>(u + 16) = lv;
+      lv.z = __builtin_bit_cast(unsigned, l2); lv.w = __builtin_bit_cast(unsigned, l3);
+      *reinterpret_cast<uint4*>(o) = hv;
+      *reinterpret_cast<uint4*>(o + 4) = lv;
     } else {
-      const int c = c4 * 4;
-      if (c + 3 < nout && (((uintptr_t)(o + c)) & 15u) == 0) {
-        f32x4 w = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(o + c) = w;
-      } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (c + k < nout) o[c + k] = v[k];
+      for (int h = 0; h < 2; ++h) {
+        const int c = lane * 8 + 4 * h;
+        const f32x4 w = h ? v1 : v0;
+        if (c + 3 < nout && (((uintptr_t)(o + 4 * h)) & 15u) == 0) {
+          *reinterpret_cast<f32x4*>(o + 4 * h) = w;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (c + k < nout) o[4 * h + k] = w[k];
+        }
       }
     }
   }
