@@ -1389,7 +1389,16 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_kernel(const float* __re
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) red[wv] = s;
   __syncthreads();
-  s = (red[0] + red[1]) + (red[2] + red[3]);
+  {
+    // (the same sum in the same order, as two plain v_add_f32: left to the vectoriser this becomes a v_pk_add_f32 that is the
+    // first reader of a ds_read2_b32 pair - the sequence that read a stale register in the lookup kernel when another
+    // kernel's MFMAs shared the SIMD, profiles/r02_kernel_anatomy.md section 7)
+    const float r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+    float s01, s23;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(s01) : "v"(r0), "v"(r1));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(s23) : "v"(r2), "v"(r3));
+    s = s01 + s23;
+  }
   const float inv = scale / s;
   float* orow = out + (int64_t)blockIdx.x * ld_out;
   const int nq = (int)(ld_out / 4);
@@ -1449,7 +1458,16 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_reg_kernel(const float* 
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) red[wv] = s;
   __syncthreads();
-  s = (red[0] + red[1]) + (red[2] + red[3]);
+  {
+    // (the same sum in the same order, as two plain v_add_f32: left to the vectoriser this becomes a v_pk_add_f32 that is the
+    // first reader of a ds_read2_b32 pair - the sequence that read a stale register in the lookup kernel when another
+    // kernel's MFMAs shared the SIMD, profiles/r02_kernel_anatomy.md section 7)
+    const float r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+    float s01, s23;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(s01) : "v"(r0), "v"(r1));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(s23) : "v"(r2), "v"(r3));
+    s = s01 + s23;
+  }
   const float inv = scale / s;
   float* orow = out + (int64_t)blockIdx.x * ld_out;
 #pragma unroll
