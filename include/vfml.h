@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 22
+#define VFML_ABI_VERSION 23
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -286,8 +286,16 @@ int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld
                          int h, int w, float* out, void* stream);
 
 /* Second pass of vfml_instnorm_stats on partial sums a convolution left behind (vfml_conv_desc.stats_part):
- * part [n][chunks][c][2] doubles -> stats [n][c][2] = {mean, 1/sqrt(var + eps)}, folded in a fixed order. */
-int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats, void* stream);
+ * part [n][chunks][c][2] doubles -> stats [n][c][2] = {mean, 1/sqrt(var + eps)}, folded in a fixed order.
+ * With many partials per channel (chunks >= 1024, c % 8 == 0) they are first folded slice-wise with coalesced reads into
+ * `workspace` (caller-owned device memory, at least vfml_instnorm_finalize_workspace_bytes(chunks, c) bytes; a larger
+ * one lets more frames of a batch go through per launch).  The route depends on (chunks, c) alone - never on n or on
+ * the workspace's size - so a frame's statistics are the same bits alone or in a batch; where the fold route applies a
+ * NULL / too small workspace is an error, not another route.  The library keeps no hidden device allocation: calls on
+ * different streams are independent as long as their workspaces are (ABI 23; until ABI 22 a per-device static scratch). */
+int64_t vfml_instnorm_finalize_workspace_bytes(int chunks, int c);   /* 0: this shape folds without a workspace */
+int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* One level of the flow-cache LOD pyramid (reference storage/cache_manager.py:77-161): out[y][x] =
  * 0.5 * (sum of the 2x2 block's in-image vectors) / (number of in-image cells); odd sides are padded

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), f"{n} declared in include/vfml.h but not exported"
     assert sorted(hip.EXPORTS) == names
     lib.vfml_abi_version.restype = ctypes.c_int
-    assert lib.vfml_abi_version() == 22
+    assert lib.vfml_abi_version() == 23
 
 
 def test_argument_validation_needs_no_gpu():
@@ -109,3 +109,41 @@ def test_no_kernel_spills_to_scratch():
             assert int(vals["private_segment_fixed_size"]) == 0, f"{name} uses {vals['private_segment_fixed_size']} B of scratch"
             assert int(vals.get("vgpr_spill_count", 0)) == 0, f"{name} spills VGPRs"
     assert seen >= 30      # conv / GEMM instantiations + the streaming kernels
+
+
+def test_no_packed_f32_first_reader_of_lds_results():
+    """Round 2's wrong-result class, closed for the whole library: with one of this library's MFMA kernels on a second
+    stream, a `v_pk_mul_f32` that was the FIRST reader of a `ds_read2_b32` result (straight behind the covering
+    `s_waitcnt lgkmcnt(0)`) read the register's previous content in lanes 48-63 (profiles/r02_kernel_anatomy.md section 7).
+    The engine runs two streams by default (encoder prefetch), so the shipped code object must not contain the pattern at
+    all: no VALU op with a 64-bit register-pair operand - packed f32, and by the same operand form f64 / 64-bit integer ops
+    - may be the first reader of a register a ds_read filled, at any distance from its wait.  Every source is built with
+    -fno-slp-vectorize (vfml/hip.py COMMON_FLAGS) and the f64 norm-statistics folds read LDS through vfml_lds_f64."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from isa_scan import scan
+    from vfml import hip
+    assert "-fno-slp-vectorize" in hip.COMMON_FLAGS
+    sites, counts = scan(hip.build(), maxd=None)
+    assert counts["kernels"] >= 100 and counts["ds_read"] >= 3000, counts       # the scan saw the library
+    assert not sites, "\n".join(f"{k}: {v[0][1]} ({len(v)} sites)" for k, v in sites.items())
+
+
+def test_isa_scan_sees_the_pattern():
+    """The scanner on the very sequence that failed (and on its repaired form)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from isa_scan import scan_disassembly
+    bad = """
+0000000000001000 <lookup>:
+\tds_read2_b32 v[20:21], v11 offset0:10 offset1:11              // 000000001000: D86E0B0A 1400000B
+\ts_waitcnt lgkmcnt(0)                                            // 000000001008: BF8CC07F
+\tv_pk_mul_f32 v[16:17], v[16:17], v[20:21]                      // 00000000100C: D3B14010 18022910
+"""
+    good = bad.replace("v_pk_mul_f32 v[16:17], v[16:17], v[20:21]", "v_mul_f32_e32 v16, v16, v20")
+    f64 = bad.replace("v_pk_mul_f32 v[16:17], v[16:17], v[20:21]", "v_add_f64 v[16:17], v[16:17], v[20:21]")
+    moved = bad.replace("\tv_pk_mul_f32", "\tv_mov_b32_e32 v22, v20                    // 0: 0\n\tv_mov_b32_e32 v23, v21      // 0: 0\n\tv_pk_mul_f32")
+    assert list(scan_disassembly(bad)[0]) == ["lookup"]
+    assert list(scan_disassembly(f64)[0]) == ["lookup"]
+    assert not scan_disassembly(good)[0]
+    assert not scan_disassembly(moved)[0]

@@ -262,8 +262,11 @@ def test_full_size_properties_1080p_and_4k_tiles(gpu):
     torch.cuda.empty_cache()
 
 
-def test_prefetched_encoders_give_the_same_fields(gpu, monkeypatch):
-    """The encoders of the NEXT window run on a side stream beside this field's update iterations (network.py
+@pytest.mark.parametrize("precision", ["f16x3", "mixed"])
+def test_prefetched_encoders_give_the_same_fields(gpu, monkeypatch, precision):
+    """(both arithmetic plans: the mixed plan - what bench.py and the CLI run by default - dispatches other kernel
+    instantiations, the one-MFMA 64-channel-step and "2a" forms, than the fp32-grade plan.)
+    The encoders of the NEXT window run on a side stream beside this field's update iterations (network.py
     prefetch_frames): the same kernels on the same inputs, so every field of a streamed 1080p clip is bit-identical to the
     one computed without the prefetch - also the field whose iterations ran beside it.  (Round 2 found the fixed-radius
     lookup returning different samples with an MFMA kernel on a second stream: profiles/r02_kernel_anatomy.md section 7.)"""
@@ -271,7 +274,7 @@ def test_prefetched_encoders_give_the_same_fields(gpu, monkeypatch):
     import io
     from processing.videoflow_processor import VideoFlowProcessor
     from vfml.synth import synthetic_clip
-    net, _ = _pair()
+    net, _ = _pair(precision=precision)
     with contextlib.redirect_stdout(io.StringIO()):
         proc = VideoFlowProcessor("cuda", sequence_length=5)
     proc.core.model = net

@@ -320,8 +320,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
     __syncthreads();
     if (rg == 0 && n0 + ch < a.cout) {
       for (int g = 1; g < RG; ++g) {
-        s1 += fold[(g * BN + ch) * 2];
-        s2 += fold[(g * BN + ch) * 2 + 1];
+        s1 += vfml_lds_f64(&fold[(g * BN + ch) * 2]);
+        s2 += vfml_lds_f64(&fold[(g * BN + ch) * 2 + 1]);
       }
       double* o = a.stats_part + ((int64_t)(m0 / BM) * a.cout + n0 + ch) * 2;
       o[0] = s1;

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(STAT_THREADS) void instnorm_partial_kernel(const fl
   for (int ch = t; ch < c; ch += STAT_THREADS) {
     double ss = 0, qq = 0;
     for (int l = 0; l < lanes; ++l) {
-      ss += sh[((int64_t)l * c + ch) * 2 + 0];
-      qq += sh[((int64_t)l * c + ch) * 2 + 1];
+      ss += vfml_lds_f64(&sh[((int64_t)l * c + ch) * 2 + 0]);
+      qq += vfml_lds_f64(&sh[((int64_t)l * c + ch) * 2 + 1]);
     }
     double* o = part + (((int64_t)n * gridDim.x + chunk) * c + ch) * 2;
     o[0] = ss;
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(FINAL_THREADS) void instnorm_final_kernel(const dou
   if (t == 0) {
     double ss = 0, qq = 0;
     for (int l = 0; l < FINAL_THREADS; ++l) {
-      ss += sh[l][0];
-      qq += sh[l][1];
+      ss += vfml_lds_f64(&sh[l][0]);
+      qq += vfml_lds_f64(&sh[l][1]);
     }
     const double mean = ss / hw;
     double var = qq / hw - mean * mean;
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void instnorm_fold_kernel(const double* __rest
   if (lane == 0) {
     double ss = 0, qq = 0;
     for (int l = 0; l < 32; ++l) {
-      ss += sh[l][ch][0];
-      qq += sh[l][ch][1];
+      ss += vfml_lds_f64(&sh[l][ch][0]);
+      qq += vfml_lds_f64(&sh[l][ch][1]);
     }
     double* o = out + (((int64_t)nn * FOLD_SLICES + sl) * c + cg * 8 + ch) * 2;
     o[0] = ss;
@@ -296,35 +296,36 @@ extern "C" int vfml_instnorm_stats(const float* x, int n, int hw, int c, float e
   return vfml_check_launch("vfml_instnorm_stats(final)");
 }
 
+static bool finalize_folds(int chunks, int c) {
+  static const int no_fold = getenv("VFML_NO_NORM_FOLD") ? atoi(getenv("VFML_NO_NORM_FOLD")) : 0;     // (A/B)
+  return !no_fold && chunks >= 1024 && c % 8 == 0;
+}
+
+extern "C" int64_t vfml_instnorm_finalize_workspace_bytes(int chunks, int c) {
+  return finalize_folds(chunks, c) ? (int64_t)FOLD_SLICES * c * 16 : 0;
+}
+
 extern "C" int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats,
-                                      void* stream) {
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
   VFML_REQUIRE(part && stats && n > 0 && chunks > 0 && c > 0 && hw > 0, "vfml_instnorm_finalize: bad argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // many partials: fold them slice-wise with coalesced reads first (scratch: 1 MiB per device, allocated on first use -
-  // the encoders run outside any stream capture; calls on one stream, as the engine makes them, are ordered)
-  constexpr int64_t SCRATCH = 1 << 20;
-  static const int no_fold = getenv("VFML_NO_NORM_FOLD") ? atoi(getenv("VFML_NO_NORM_FOLD")) : 0;     // (A/B)
+  // many partials: fold them slice-wise with coalesced reads first, through the CALLER's workspace.
   // (the route depends on chunks and c only - never on n: a frame's statistics are the same bits whether it is encoded
-  // alone or in a batch; batches larger than the scratch go through it a few frames at a time)
-  const int64_t per_frame = (int64_t)FOLD_SLICES * c * 16;
-  if (!no_fold && chunks >= 1024 && c % 8 == 0 && per_frame <= SCRATCH) {
-    static double* scratch[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-      if (!scratch[dev] && hipMalloc(&scratch[dev], SCRATCH) != hipSuccess) scratch[dev] = nullptr;
-      if (scratch[dev]) {
-        const int nmax = (int)(SCRATCH / per_frame);
-        for (int n0 = 0; n0 < n; n0 += nmax) {
-          const int nb = n - n0 < nmax ? n - n0 : nmax;
-          hipLaunchKernelGGL(instnorm_fold_kernel, dim3(nb * (c / 8) * FOLD_SLICES), dim3(256), 0, st,
-                             part + (int64_t)n0 * chunks * c * 2, chunks, c, scratch[dev]);
-          hipLaunchKernelGGL(instnorm_final_kernel, dim3(nb * c), dim3(FINAL_THREADS), 0, st, (const double*)scratch[dev], nb,
-                             FOLD_SLICES, c, hw, eps, stats + (int64_t)n0 * c * 2);
-        }
-        return vfml_check_launch("vfml_instnorm_finalize");
-      }
+  // alone or in a batch; batches larger than the workspace go through it a few frames at a time)
+  if (finalize_folds(chunks, c)) {
+    const int64_t per_frame = (int64_t)FOLD_SLICES * c * 16;
+    VFML_REQUIRE(workspace && workspace_bytes >= per_frame && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0,
+                 "vfml_instnorm_finalize: %d partials x %d channels fold through a workspace of >= %lld bytes (16-byte aligned); got %lld",
+                 chunks, c, (long long)per_frame, (long long)(workspace ? workspace_bytes : 0));
+    const int nmax = (int)(workspace_bytes / per_frame);
+    for (int n0 = 0; n0 < n; n0 += nmax) {
+      const int nb = n - n0 < nmax ? n - n0 : nmax;
+      hipLaunchKernelGGL(instnorm_fold_kernel, dim3(nb * (c / 8) * FOLD_SLICES), dim3(256), 0, st,
+                         part + (int64_t)n0 * chunks * c * 2, chunks, c, (double*)workspace);
+      hipLaunchKernelGGL(instnorm_final_kernel, dim3(nb * c), dim3(FINAL_THREADS), 0, st, (const double*)workspace, nb,
+                         FOLD_SLICES, c, hw, eps, stats + (int64_t)n0 * c * 2);
     }
-    (void)hipGetLastError();
+    return vfml_check_launch("vfml_instnorm_finalize");
   }
   hipLaunchKernelGGL(instnorm_final_kernel, dim3(n * c), dim3(FINAL_THREADS), 0, st, part, n, chunks,
                      c, hw, eps, stats);

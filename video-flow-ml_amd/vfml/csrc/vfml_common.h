@@ -26,6 +26,25 @@ __device__ __forceinline__ void vfml_split2(float a, float b, vfml_h16x2& h, vfm
   l = ll;
 }
 
+// A double read from LDS whose FIRST reader is a 32-bit VALU move per half, not the 64-bit-operand consumer itself.
+// Round 2's two-stream finding (profiles/r02_kernel_anatomy.md section 7): a packed-f32 op - a 64-bit register-pair operand
+// read straight out of a ds_read result - saw stale lanes 48-63 beside another stream's MFMA kernels.  v_add_f64 takes its
+// operand the same way, and the norm statistics' LDS folds run on the prefetch stream beside the iterations' MFMA kernels;
+// no disturbance of them was ever observed, but the cause is not established, so no 64-bit-operand VALU op of this library
+// is the first reader of an LDS result (tests/test_abi.py scans the code object for both forms).  Two v_mov_b32 per fold
+// term: nothing, next to the LDS round trip it follows.
+__device__ __forceinline__ double vfml_lds_f64(const double* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  unsigned lo, hi;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "v"(u.x));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "v"(u.y));
+  return __hiloint2double((int)hi, (int)lo);
+#else
+  return *p;
+#endif
+}
+
 void vfml_set_error(const char* fmt, ...);
 
 #define VFML_REQUIRE(cond, ...)            \

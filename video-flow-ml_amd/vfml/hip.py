@@ -44,11 +44,16 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
-# Per-source compiler flags.  flow_ops.hip is built without the SLP vectoriser: left on, it pairs the bilinear mix of the
-# correlation lookup into v_pk_mul_f32 / v_pk_add_f32 reading ds_read results straight behind their s_waitcnt, and on gfx950
-# such a packed op read a stale register in lanes 48-63 whenever one of this library's MFMA kernels ran on another stream
-# (profiles/r02_kernel_anatomy.md section 7; tools/exp/two_stream_lookup_diag.py shows it, scan_pk_after_lds.py lists the sites).
-EXTRA_FLAGS = {"flow_ops.hip": ["-fno-slp-vectorize"]}
+# Every source is built without the SLP vectoriser.  Left on, it pairs adjacent scalar f32 multiplies / adds into
+# v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32; where such a packed op was the FIRST reader of a ds_read result, straight behind
+# the s_waitcnt that covers it, the correlation lookup read a stale register in lanes 48-63 whenever one of this library's
+# MFMA kernels ran on another stream (profiles/r02_kernel_anatomy.md section 7) - and the engine runs two streams by default
+# (the encoder prefetch).  Round 2 closed the one observed instance; round 3 closes the class: no packed-f32 first reader of
+# an LDS result anywhere in the shipped code object (tests/test_abi.py::test_no_packed_f32_first_reader_of_lds_results).
+# Packed f32 ops beside MFMAs are an anti-lever anyway (MI355X_MICROARCH.md, cycle constants: 2 v_pk_add_f32 per MFMA gap
+# cost +26 cycles against 2 v_fma_f32).
+COMMON_FLAGS = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {}
 
 
 def build(force=False, verbose=False):
@@ -68,7 +73,7 @@ def build(force=False, verbose=False):
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
-            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + [
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + COMMON_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + [
                 "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
@@ -113,7 +118,9 @@ def lib():
     L.vfml_softmax_rows_f16.argtypes = [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_float, c_void_p]
     L.vfml_transpose_to_s16.argtypes = [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]
     L.vfml_add_to_s16.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]
-    L.vfml_instnorm_finalize.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
+    L.vfml_instnorm_finalize.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]
+    L.vfml_instnorm_finalize_workspace_bytes.restype = c_int64
+    L.vfml_instnorm_finalize_workspace_bytes.argtypes = [c_int, c_int]
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
@@ -136,7 +143,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 22:
+    if L.vfml_abi_version() != 23:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -145,7 +152,7 @@ def lib():
 EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
-    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
+    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
     "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_flow_rows7",
     "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
@@ -403,9 +410,20 @@ def instnorm_stats(x, n, hw, c, stats, workspace, eps=1e-5):
                                      c_void_p(workspace.data_ptr()), _stream()), "vfml_instnorm_stats")
 
 
-def instnorm_finalize(part, n, chunks, c, hw, stats, eps=1e-5):
-    """Fold the partial sums a convolution left in `part` (conv2d(..., stats_part=part)) into {mean, rstd}."""
-    _check(lib().vfml_instnorm_finalize(c_void_p(part.data_ptr()), n, chunks, c, hw, eps, _ptr(_dev(stats)), _stream()),
+def instnorm_finalize_workspace_bytes(chunks, c):
+    return int(lib().vfml_instnorm_finalize_workspace_bytes(chunks, c))
+
+
+def instnorm_finalize(part, n, chunks, c, hw, stats, eps=1e-5, workspace=None):
+    """Fold the partial sums a convolution left in `part` (conv2d(..., stats_part=part)) into {mean, rstd}.
+    workspace: a float64 device tensor for the slice-wise first pass over many partials (instnorm_finalize_workspace_bytes;
+    None: one is taken from torch's allocator for this call - stream-ordered, so concurrent streams never share it)."""
+    need = instnorm_finalize_workspace_bytes(chunks, c)
+    if need and (workspace is None or workspace.numel() * 8 < need):
+        workspace = torch.empty(min(n, 8) * need // 8, dtype=torch.float64, device=stats.device)
+    _check(lib().vfml_instnorm_finalize(c_void_p(part.data_ptr()), n, chunks, c, hw, eps, _ptr(_dev(stats)),
+                                        c_void_p(workspace.data_ptr()) if workspace is not None else None,
+                                        workspace.numel() * 8 if workspace is not None else 0, _stream()),
            "vfml_instnorm_finalize")
 
 

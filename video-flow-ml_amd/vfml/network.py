@@ -237,7 +237,7 @@ class MOFNetHIP(_Holder):
         elif p == "f16":
             nm = 1
         else:
-            plan = getattr(self.cfg, "mfma_plan", None) or {}
+            plan = self._mixed_plan()
             best, nm = -1, 3
             for prefix, n in plan.items():
                 if layer.startswith(prefix) and len(prefix) > best:
@@ -250,13 +250,22 @@ class MOFNetHIP(_Holder):
             nm = 3       # a volume and its transpose must stay the same numbers: the symmetric forms only
         return nm
 
+    def _mixed_plan(self):
+        """cfg.mfma_plan, or - as vfml/cfg.py says - DEFAULT_MIXED_PLAN when precision is 'mixed' and none is given
+        (an explicit empty dict means "3 everywhere")."""
+        plan = getattr(self.cfg, "mfma_plan", None)
+        if plan is None:
+            from .cfg import DEFAULT_MIXED_PLAN
+            plan = DEFAULT_MIXED_PLAN
+        return plan
+
     def _plan_key(self):
         """The arithmetic as part of a cached frame's identity."""
         p = self._precision()
         vol = getattr(self.cfg, "corr_volume", "f32")
         if vol not in ("f32", "f16"):
             raise ValueError(f"cfg.corr_volume must be 'f32' or 'f16', got {vol!r}")
-        key = (p, tuple(sorted((k, str(v)) for k, v in (getattr(self.cfg, "mfma_plan", None) or {}).items()))) if p == "mixed" else p
+        key = (p, tuple(sorted((k, str(v)) for k, v in self._mixed_plan().items()))) if p == "mixed" else p
         if self._tile() is None:
             key = (key, "row-major")
         return key if vol == "f32" else (key, vol)
@@ -357,6 +366,9 @@ class MOFNetHIP(_Holder):
         AF = hip.FMT_S16 if (split_prec and self._enc_split_rows()) else hip.FMT_F32
         part_len = n * ((h2 * w2 + 31) // 32) * 64 * 2            # largest layer: half resolution, 64 channels
         parts = self._buf("enc_part", 3 * part_len, dev, torch.float64) if split_prec else None
+        # (the norm fold's first pass; like every encoder workspace it belongs to this engine, and whatever runs the
+        # encoders on another stream - prefetch_frames - is ordered against the main stream's use by _join_prefetch)
+        fold_ws = self._buf("enc_foldws", min(n, 8) * 64 * 128 * 2, dev, torch.float64) if split_prec else None
 
         def conv_stats(src, c, hh_, ww_, name, planes, dst, slot, k, stride=1, pad=0, src_fmt=hip.FMT_F32):
             wgt, b = P[name]
@@ -373,7 +385,7 @@ class MOFNetHIP(_Holder):
             hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
                        stats_part=part, mfma=nm, in_fmt=src_fmt)
             s = st[slot * n * 128 * 2:]
-            hip.instnorm_finalize(part, n, chunks, planes, hw, s)
+            hip.instnorm_finalize(part, n, chunks, planes, hw, s, workspace=fold_ws)
             return s
 
         s0 = conv_stats(x, 4, H, W, f"{prefix}.conv1", 64, raw, 0, 7, stride=2, pad=3)
