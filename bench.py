@@ -368,20 +368,8 @@ def hbm_traffic_from_profiles(kernel, workload):
 
 
 def host_cpu_share(cap=16):
-    """CPUs this process may actually use: scheduler affinity, cgroup-v2 quota, capped (os.cpu_count()
-    reports the whole host, and oversubscribing a 16-CPU share with 100+ threads is far slower)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, cap))
+    from vfml.dist import host_cpu_share as share
+    return share(cap)
 
 
 def cpu_baseline(args, proc, clip_np, field_idx, T):

@@ -398,3 +398,32 @@ def test_async_cache_writer_writes_what_the_sync_path_writes(tmp_path):
     bad.submit(flows[0], 0)
     with pytest.raises(Exception):
         bad.close()
+
+
+@pytest.mark.parametrize("mode", ["huffman", "stored", "zlib"])
+def test_npz_writer_modes_read_back_like_savez_compressed(tmp_path, mode):
+    """storage.cache_manager.write_npz (VFML_NPZ_DEFLATE): whatever produces the deflate stream, np.load - the reference's
+    reader, storage/cache_manager.py:67-70 - sees the members np.savez_compressed (:47, :262) would have stored: same
+    names in the same order, dtypes, shapes (0-d scalars stay 0-d) and values; the archive passes zipfile's CRC check."""
+    import zipfile
+    from storage.cache_manager import write_npz
+    rng = np.random.default_rng(11)
+    flow = rng.standard_normal((37, 53, 2)).astype(np.float32)
+    members = {'flow': flow, 'frame_idx': 7, 'shape': flow.shape, 'dtype': str(flow.dtype), 'lod_level': 2,
+               'min_flow': float(flow.min()), 'strided': flow[:, ::2], 'empty': np.zeros((0, 2), np.float32)}
+    ref, got = str(tmp_path / "ref.npz"), str(tmp_path / "got.npz")
+    np.savez_compressed(ref, **members)
+    write_npz(got, members, mode)
+    a, b = np.load(ref), np.load(got)
+    assert a.files == b.files
+    for k in a.files:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    with zipfile.ZipFile(got) as z:
+        assert z.testzip() is None
+        assert [i.filename for i in z.infolist()] == [k + ".npy" for k in members]
+    if mode == "huffman":       # an entropy-coded stream, not a stored one: the cache keeps its compressed size
+        big = np.zeros((64, 64, 2), np.float32)
+        write_npz(str(tmp_path / "z.npz"), {'flow': big}, mode)
+        assert os.path.getsize(tmp_path / "z.npz") < big.nbytes // 4
+    with pytest.raises(ValueError):
+        write_npz(got, members, "lzma")

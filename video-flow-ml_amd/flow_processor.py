@@ -202,30 +202,49 @@ def main(argv=None):
     proc = eng.get_processor()
     feeder = ClipFeeder(frames, device)     # frames go up through a pinned ring while earlier fields compute
     save_format = args.save_flow or 'npz'
-    # rank 0 owns the cache files; the writer's threads compress finished fields while the GPU computes the
-    # next ones (one rank, whole frames) or after the gather (several ranks / tiles)
-    writer = AsyncFlowCacheWriter(cache_dir, save_format, workers=min(16, os.cpu_count() or 1),
-                                  num_lods=0 if args.skip_lods else 5, manager=mgr) if rank == 0 else None
+    tiled = bool(args.tile and not memflow)
+    num_lods = 0 if args.skip_lods else 5
+    gpu_lods = 0 if (args.skip_lods or save_format == 'flo') else 5
+    # Whole-frame jobs: EVERY rank writes the cache files of its own fields (one node = one filesystem; the reference's
+    # cache is a directory of per-frame files, storage/cache_manager.py:247-262) - no gather, and the writers' compression
+    # threads scale with the GPUs instead of funnelling every field into rank 0's.  Tiled jobs: tiles of one frame come
+    # from several ranks, so they stream to rank 0 (chunked gathers), which pastes and writes.
+    per_rank = not tiled
+    cpus = max(1, vdist.host_cpu_share() // (world if per_rank else 1))
+    writer = AsyncFlowCacheWriter(cache_dir, save_format, workers=min(16, cpus), num_lods=num_lods,
+                                  manager=mgr) if (per_rank or rank == 0) else None
     t0 = time.time()
     # LOD levels are reduced on the GPU that computed the field (bit-identical to the reference's loop) and travel
     # with it; tiled frames are assembled on rank 0 and reduced by the writer's threads
-    run_sharded(proc, None, range(n), tile_mode=args.tile and not memflow, rank=rank, world=world, feeder=feeder,
-                on_field=(lambda k, field, lods: writer.submit(field, k, lods)) if writer is not None else None,
-                collect=False, num_lods=0 if (args.skip_lods or save_format == 'flo') else 5)
+    sink = (lambda k, field, lods: writer.submit(field, k, lods)) if writer is not None else None
+    if per_rank:
+        run_sharded(proc, None, range(n), tile_mode=False, rank=rank, world=world, feeder=feeder, local_sink=sink,
+                    collect=False, num_lods=gpu_lods)
+    else:
+        run_sharded(proc, None, range(n), tile_mode=True, rank=rank, world=world, feeder=feeder, on_field=sink,
+                    collect=False, num_lods=gpu_lods)
     if str(device).startswith('cuda'):
         torch.cuda.synchronize()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()                 # every rank's fields are computed and handed to a writer
     dt = time.time() - t0
+    if writer is not None:
+        writer.close()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()                 # every rank's files are on disk
     if rank == 0:
+        dt_all = time.time() - t0
         log(f"{n} flow fields ({width}x{height}, seq {args.sequence_length}) in {dt:.2f} s = {n / dt:.2f} fields/s "
             f"on {world} GPU(s)")
-        writer.close()
-        dt_all = time.time() - t0
         log(f"Flow cache written: {cache_dir} ({n / max(dt_all, 1e-9):.1f} fields/s end to end, incl. "
             f"{'no ' if args.skip_lods else ''}LODs)")
+        complete, _, missing = mgr.check_cache_exists(cache_dir, n)
+        if not complete:
+            log(f"Error: flow cache incomplete after the job, missing frames {missing[:8]}{'...' if len(missing) > 8 else ''}")
+            return 1
         if not args.interactive:
             log("note: video encoding / composition is out of scope for this build; the flow cache is the output")
     if torch.distributed.is_initialized():
-        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return 0
 

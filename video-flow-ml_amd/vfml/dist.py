@@ -34,6 +34,23 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def host_cpu_share(cap=None):
+    """CPUs this process may actually use: scheduler affinity and the cgroup-v2 quota (os.cpu_count() reports the whole
+    host, and a 16-CPU share oversubscribed with 100+ threads is far slower than 16 threads)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap) if cap else n)
+
+
 def shard_bounds(num_items, rank, world):
     """Contiguous, balanced block [lo, hi) of `num_items` for `rank` (first num_items % world ranks
     get one extra item). Contiguity keeps a rank's sliding frame windows overlapping."""
