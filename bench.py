@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f16x3", "f16x2", "f16", "mixed", "f32"],
                     help="arithmetic of the engine (vfml/cfg.py); default: f16x3, and f16 for bof720p (BASELINE config 5 "
                          "is quoted in fp16)")
-    ap.add_argument("--corr-volume", default=None, choices=["f32", "f16"],
+    ap.add_argument("--corr-volume", default=None, choices=["f32", "f16", "f16@1", "f16@2", "f16@3"],
                     help="storage of the correlation pyramids (vfml/cfg.py corr_volume; default f32; f16 is the opt-in "
                          "half-size volume, ~1e-4 px against the oracle at 1080p)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,10 +80,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads for the CPU baseline (0 = this process's CPU share: affinity / cgroup quota, "
                          "capped at 16 - the per-GPU share of the pool's boxes)")
-    ap.add_argument("--cpu-sample-height", type=int, default=816,
-                    help="CPU-baseline sample: one field on a centre crop of this height (16:9; 816 -> 1440x816, about "
-                         "15 s of CPU work), scaled to full size by the analytic FLOP ratio; 0 = one full-size field "
-                         "(about 40 s)")
+    ap.add_argument("--cpu-sample-height", type=int, default=0,
+                    help="CPU-baseline sample: 0 (default) = one full-size field of the workload (about 40 s of CPU work "
+                         "at 1080p on 16 threads; the line then carries an engine-vs-oracle check at the headline size); "
+                         "N = one field on a 16:9 centre crop of that height, scaled to full size by the analytic FLOP ratio")
+    ap.add_argument("--no-jobs", action="store_true",
+                    help="skip the whole-job figures (job_300, cli_e2e: fresh child processes, about a minute more)")
     args = ap.parse_args()
 
     if args.workload == "mof4k-tile":
@@ -157,9 +159,14 @@ def main():
     per_rank = Wm + K + En + An + Pn
     # the job is one clip of world * per_rank fields; every rank holds it in host memory (same synthetic generator on
     # every rank - no input exchange) and feeds its own frame range to its GPU as its fields come up
-    clip_np = synthetic_clip(world * per_rank + T - 1, args.height, args.width)
+    # (only ITS stretch of it: frame t of the synthetic clip depends on t alone, and a rank never reads another rank's
+    # frames - the other entries stay None and are never uploaded)
+    total_frames = world * per_rank + T - 1
     half = T // 2
     mine = [rank * per_rank + half + i for i in range(per_rank)]       # this rank's fields (full windows)
+    lo_f, hi_f = mine[0] - half, mine[-1] + half + 1
+    clip_np = [None] * total_frames
+    clip_np[lo_f:hi_f] = synthetic_clip(hi_f - lo_f, args.height, args.width, start=lo_f)
 
     # -- CPU baseline (oracle) on a bounded sample of the same workload: BEFORE anything is timed (and before the
     #    engine's buffers are sized for the full frame) ----------------------------------------------------------------
@@ -287,6 +294,8 @@ def main():
                                + f" seq_len={T} {args.width}x{args.height} synthetic clip, decoder_depth={depth}, "
                                  f"seeded weights",
                    "fields_per_gpu": K, "clip_frames": len(clip_np), "parallelism": f"frames-dp{world}",
+                   "cli_default_precision": "mixed (processing/videoflow_core.py: what flow_processor.py and the "
+                                            "VideoFlowProcessor API run unless VFML_PRECISION says otherwise)",
                    "corr_volume": getattr(core.cfg, "corr_volume", "f32"),
                    "inputs": "uint8 frames in host memory (uploaded inside the timed region through a pinned ring)",
                    "outputs": "[H,W,2] f32 fields in rank-0 host memory (pinned D2H of field i under field i+1"
@@ -342,9 +351,40 @@ def main():
         }
     if result_cpu is not None:
         result["cpu_baseline"] = result_cpu
+    # -- the whole job (BASELINE config 2: a 300-frame clip), cold start included, and the drop-in CLI with its cache writer:
+    #    fresh child processes, after everything above (this process's engine is released first) ------------------------
+    if args.workload == "mof1080p" and world == 1 and not args.no_jobs:
+        core.model.release_workspace()
+        del feeder
+        from vfml.runner import release_buffers
+        release_buffers()
+        torch.cuda.empty_cache()
+        result.update(whole_jobs(precision))
     print(json.dumps(result))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def whole_jobs(precision):
+    """job_300 / cli_e2e (tools/job_bench.py, one fresh process each): {"job_300": {...}, "cli_e2e": {...}}."""
+    import subprocess
+    env = dict(os.environ, VFML_PRECISION=precision or "mixed")
+    out = {}
+
+    def run(*argv):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "job_bench.py"), *argv], env=env,
+                               capture_output=True, text=True, timeout=420)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode == 0 and line:
+                return json.loads(line[-1])
+            return {"error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"}
+        except subprocess.TimeoutExpired:
+            return {"error": "timeout"}
+
+    out["job_300"] = run("job300")
+    out["cli_e2e"] = {"skip_lods": run("cli"), "lods": run("cli", "--lods")}
+    return out
 
 
 def hbm_traffic_from_profiles(kernel, workload):

@@ -241,7 +241,9 @@ int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* 
 /* out_fmt VFML_FMT_S16: channels are written as split rows; the channel count is rounded up to a
  * multiple of 8 with zero channels (out is 32-byte aligned, ld_out % 8 == 0).
  * vol_fmt VFML_FMT_F32, or VFML_FMT_F16: the pyramids hold one f16 per element (ld in elements; radius 3 or 4, at most four
- * levels). */
+ * levels), or VFML_VOL_F16_LEVELS(m): only the levels whose bit is set in m do (m = 14: levels 1-3, 12: levels 2-3, 8: level
+ * 3; the coarse levels cost the fewest bits of the flow and the lookup reads as many texels of each level as of level 0). */
+#define VFML_VOL_F16_LEVELS(m) (0x100 | (m))
 
 /* The same lookup with the pyramid pointers read from a DEVICE table at run time: table[m * levels + l] is what
  * pyr[m * levels + l] is above.  A launch recorded in a HIP graph (the update iterations of a field are a fixed launch

@@ -1065,6 +1065,20 @@ def test_corr_lookup_reads_f16_volumes(gpu, radius, levels):
         assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match="vol_fmt"):
         hip.corr_lookup([_as_f32_storage(v) for v in vol16], hl, wl, ld, 2, P, coords, 0, 4, a, 0, ldo, vol_fmt=hip.FMT_F16)
+    # VFML_VOL_F16_LEVELS(m): only the levels of m hold f16 texels (cfg.corr_volume 'f16@k': levels k.. of the pyramid)
+    for mask in (14, 12, 8):
+        m = mask & ((1 << levels) - 1)
+        if m == 0:
+            continue
+        mixed = [_as_f32_storage(vol16[l]) if (m >> l) & 1 else vol32[l] for l in range(levels)]
+        for fmt in (hip.FMT_F32, hip.FMT_S16):
+            a = torch.zeros(P * ldo, device=gpu)
+            b = torch.zeros(P * ldo, device=gpu)
+            hip.corr_lookup(vol32, hl, wl, ld, radius, P, coords, 0, 4, a, 0, ldo, out_fmt=fmt)
+            hip.corr_lookup(mixed, hl, wl, ld, radius, P, coords, 0, 4, b, 0, ldo, out_fmt=fmt, vol_fmt=hip.vol_f16_levels(mask))
+            assert torch.equal(a, b), (mask, fmt)
+    with pytest.raises(RuntimeError, match="vol_fmt"):
+        hip.corr_lookup(vol32, hl, wl, ld, radius, P, coords, 0, 4, a, 0, ldo, vol_fmt=hip.vol_f16_levels(5))
 
 
 @pytest.mark.parametrize("dual", [False, True])

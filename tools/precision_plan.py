@@ -32,7 +32,32 @@ LAYERS = [f"{UB}.encoder.convc1", f"{UB}.encoder.convc2", f"{UB}.encoder.convf1"
           "fnet", "cnet", "corr"]
 
 
+# Candidate plans for a plain-f16-grade arithmetic that stays inside the 1e-3 px contract (BASELINE config 5, "fp16"): one MFMA
+# per product wherever the rounding of a WEIGHT does not reach the flow linearly; the context encoder (1.4e-3 px on its own at
+# 1080p), the per-frame context parts of the gates and the feature encoder keep all three terms (they run once per frame, not
+# per iteration); the layers on the linear flow path take their activations as plain f16 and keep the weights' lo half ("2a").
+_KEEP3 = {"cnet": 3, "fnet": 3, f"{UB}.gru.convzr1.ctx": 3, f"{UB}.gru.convq1.ctx": 3, f"{UB}.gru.convzr2.ctx": 3,
+          f"{UB}.gru.convq2.ctx": 3}
+CANDIDATES = {
+    "all-1": {"": 1},
+    "all-1, cnet 3": {"": 1, "cnet": 3},
+    "all-1, encoders+ctx 3": {"": 1, **_KEEP3},
+    "P1: + conv, fh1 at 2a": {"": 1, **_KEEP3, f"{UB}.encoder.conv": "2a", f"{UB}.flow_head.conv1": "2a"},
+    "P2: + convc2, fh2 at 2a": {"": 1, **_KEEP3, f"{UB}.encoder.conv": "2a", f"{UB}.flow_head.conv1": "2a",
+                               f"{UB}.encoder.convc2": "2a", f"{UB}.flow_head.conv2": "2a"},
+    "P3: P2 + convc1, q2 at 2a": {"": 1, **_KEEP3, f"{UB}.encoder.conv": "2a", f"{UB}.flow_head.conv1": "2a",
+                                 f"{UB}.encoder.convc2": "2a", f"{UB}.flow_head.conv2": "2a",
+                                 f"{UB}.encoder.convc1": "2a", f"{UB}.gru.convq2.iter": "2a"},
+    "P4: P3, fnet at 1": {"": 1, **_KEEP3, "fnet": 1, f"{UB}.encoder.conv": "2a", f"{UB}.flow_head.conv1": "2a",
+                          f"{UB}.encoder.convc2": "2a", f"{UB}.flow_head.conv2": "2a",
+                          f"{UB}.encoder.convc1": "2a", f"{UB}.gru.convq2.iter": "2a"},
+    "MOF default mixed plan": None,       # filled in main()
+}
+
+
 def main():
+    from vfml.cfg import DEFAULT_MIXED_PLAN
+    CANDIDATES["MOF default mixed plan"] = dict(DEFAULT_MIXED_PLAN)
     ap = argparse.ArgumentParser()
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -40,11 +65,16 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--budget", type=float, default=5e-5, help="mean EPE (px) the greedy plan may spend")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--arch", default="mof", choices=["mof", "bof"], help="bof: the tri-frame network (centre triple of the window)")
+    ap.add_argument("--candidates", action="store_true",
+                    help="skip the per-layer sweep: measure the named candidate plans (CANDIDATES) against the all-3 field")
     args = ap.parse_args()
 
     cfg = get_cfg()
     cfg.precision = "mixed"
     cfg.mfma_plan = {}
+    if args.arch == "bof":
+        cfg.network = "BOFNet"
     net = build_network(cfg)
     net.load_state_dict(seeded_state_dict(cfg, args.seed))
     net.cuda().eval()
@@ -55,7 +85,8 @@ def main():
         cfg.mfma_plan = dict(plan)
         net.clear_feature_cache()
         f, _ = net.forward_u8(clip[start:start + args.seq], return_lowres=False, pick_only=True)
-        return f[0, 0].permute(1, 2, 0).clone()
+        # (pick_only: [1, 1, 2, H, W]; the tri-frame network returns both flows - the reference's pick is shape[1] // 2)
+        return f[0, f.shape[1] // 2].permute(1, 2, 0).clone()
 
     def timed(plan):
         """ms per field in the sliding steady state (encoders / pyramids of the overlap cached, as in a job)."""
@@ -77,8 +108,18 @@ def main():
 
     ref = field({})
     t_ref = timed({})
-    print(f"{args.width}x{args.height} seq {args.seq} seed {args.seed}: all-3 field {t_ref:.2f} ms (steady state), "
+    print(f"{args.arch} {args.width}x{args.height} seq {args.seq} seed {args.seed}: all-3 field {t_ref:.2f} ms (steady state), "
           f"|flow| mean {float(ref.abs().mean()):.3f} px")
+    if args.candidates:
+        out = {}
+        for name, plan in CANDIDATES.items():
+            e, t = epe(field(plan), ref), timed(plan)
+            out[name] = {"plan": plan, "epe_vs_all3": e, "ms": t}
+            print(f"  {name:28s}: dEPE {e:.3e} px vs all-3, field {t:7.2f} ms (all-3 {t_ref:.2f})", flush=True)
+        if args.json:
+            with open(args.json, "w") as f:
+                json.dump({"args": vars(args), "t_ref_ms": t_ref, "candidates": out}, f, indent=1)
+        return
     rows = []
     for layer in LAYERS:
         for n in (2, "2a", 1):

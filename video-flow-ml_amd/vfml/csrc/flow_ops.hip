@@ -27,7 +27,7 @@ struct LookupArgs {
   const float* coords; int ld_coords;
   float* out; int ld_out;
   int out16;
-  int vol16;     // the pyramids hold one f16 per element (VFML_FMT_F16; fixed-radius kernels only)
+  int vol16;     // bit l: level l of the pyramids holds one f16 per element (VFML_FMT_F16 / VFML_VOL_F16_LEVELS; fixed-radius kernels only)
   int tws, ths;  // vol_tile: a level image (and the query grid that orders the rows) stored in (1<<tws) x (1<<ths) tiles; 0, 0: row-major
   int qw;        // width of the query grid (= wl[0]) when tiled: query q reads volume row tiled_at(q / qw, q % qw)
 };
@@ -155,7 +155,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   mix       lane (level, x offset) walks its column of 2R+1 samples downwards: the lower texel pair of one sample is the
 //             upper pair of the next (one ds_read2 and four multiply-adds per sample, no index arithmetic)
 //   store     the samples go through LDS so that a lane owns one 8-channel unit: 32 bytes of split row (or two quads of f32)
-template <int R, bool OUT16, bool VOL16 = false>
+//   V16       bit l set: level l of the volumes holds f16 texels (a compile-time property of each unrolled level)
+template <int R, bool OUT16, int V16 = 0>
 __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(const LookupArgs a) {
   constexpr int SIDE = 2 * R + 2, PSZ = SIDE * SIDE, WIN = 2 * R + 1, WW = WIN * WIN;
   constexpr int NOUTPAD = (FIXED_LEVELS * WW + 7) & ~7;
@@ -172,7 +173,6 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
   const int qrow = __builtin_amdgcn_readfirstlane((a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq);
   const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
   const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
-  constexpr int ES = VOL16 ? 2 : 4;        // bytes per texel of the volume
   // the two passes of a level: window cells lane and lane + 64 (the second pass: cells 64 .. PSZ-1)
   const int pyA = lane / SIDE, pxA = lane - pyA * SIDE;
   const int pyB = (lane + 64) / SIDE, pxB = (lane + 64) - pyB * SIDE;
@@ -194,6 +194,8 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
   for (int l = 0; l < FIXED_LEVELS; ++l) {
     const bool have = l < a.levels;
     const int ll = have ? l : 0;
+    const bool v16 = (V16 >> l) & 1;         // (l is unrolled: a constant per copy of the body)
+    const int ES = v16 ? 2 : 4;              // bytes per texel of this level
     const char* base = reinterpret_cast<const char*>(pl[l]) + (int64_t)qrow * a.ld[ll] * ES;
     const int wl = a.wl[ll], hl = a.hl[ll];
     const float inv = __builtin_bit_cast(float, (127 - l) << 23);      // 2^-l, exactly what 1.0f / (1 << l) is
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
       ok = have && in && xx >= 0 && xx < wl && yy >= 0 && yy < hl;
       const int at = tiled_at(min(max(yy, 0), hl - 1), min(max(xx, 0), wl - 1), wl, a.tws, a.ths);
       // (explicitly GLOBAL: a pointer that went through selects or a table loses its address space and becomes flat_load)
-      if constexpr (VOL16) out = (float)((const __attribute__((address_space(1))) _Float16*)base)[at];
+      if (v16) out = (float)((const __attribute__((address_space(1))) _Float16*)base)[at];
       else out = ((const __attribute__((address_space(1))) float*)base)[at];          // (zeroed below, once every load is on its way)
     };
     texel(pxA, pyA, true, va[l], oka[l]);
@@ -480,8 +482,17 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
   VFML_REQUIRE(nmaps >= 1 && nmaps <= MAX_MAPS && q_per_map > 0, "vfml_corr_lookup: nmaps=%d out of [1,%d] or empty maps", nmaps, MAX_MAPS);
   const int nq = nmaps * q_per_map;
   VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
-  VFML_REQUIRE(vol_fmt == VFML_FMT_F32 || (vol_fmt == VFML_FMT_F16 && (radius == 3 || radius == 4) && levels <= FIXED_LEVELS),
-               "vfml_corr_lookup: vol_fmt is VFML_FMT_F32, or VFML_FMT_F16 with radius 3 / 4 and at most %d levels", FIXED_LEVELS);
+  // f16 levels as a mask: VFML_FMT_F16 = every level; VFML_VOL_F16_LEVELS(m) = the levels of m (the forms built: all, all
+  // but level 0, levels 2-3, level 3)
+  int v16mask = vol_fmt == VFML_FMT_F16 ? 15 : ((vol_fmt & ~15) == VFML_VOL_F16_LEVELS(0) ? (vol_fmt & 15) : (vol_fmt == VFML_FMT_F32 ? 0 : -1));
+  if (v16mask > 0 && levels >= 1 && levels <= FIXED_LEVELS) {
+    v16mask &= (1 << levels) - 1;                                  // levels the pyramid does not have do not count ...
+    if (v16mask) v16mask |= 15 & ~((1 << levels) - 1);             // ... and take whatever form is built
+  }
+  VFML_REQUIRE(v16mask == 0 || ((radius == 3 || radius == 4) && levels <= FIXED_LEVELS &&
+                                (v16mask == 15 || v16mask == 14 || v16mask == 12 || v16mask == 8)),
+               "vfml_corr_lookup: vol_fmt is VFML_FMT_F32, or (radius 3 / 4, at most %d levels) VFML_FMT_F16 or "
+               "VFML_VOL_F16_LEVELS(m) with m = levels 1-3, 2-3 or 3", FIXED_LEVELS);
   VFML_REQUIRE(hl && wl && ld && coords && out, "vfml_corr_lookup: null pointer");
   VFML_REQUIRE(levels >= 1 && levels <= MAX_LEVELS, "vfml_corr_lookup: levels=%d out of [1,%d]", levels, MAX_LEVELS);
   VFML_REQUIRE(radius >= 1 && radius <= MAX_RADIUS, "vfml_corr_lookup: radius=%d out of [1,%d]", radius, MAX_RADIUS);
@@ -493,7 +504,7 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
                  "vfml_corr_lookup: split-row output needs a 32-byte aligned out and ld_out %% 8 == 0");
   LookupArgs a;
   a.out16 = out_fmt == VFML_FMT_S16;
-  a.vol16 = vol_fmt == VFML_FMT_F16;
+  a.vol16 = v16mask;
   a.table = table;
   for (int m = 0; m < MAX_MAPS; ++m)
     for (int l = 0; l < MAX_LEVELS; ++l) a.pyr[m][l] = nullptr;
@@ -520,13 +531,22 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int generic = getenv("VFML_LOOKUP_GENERIC") ? atoi(getenv("VFML_LOOKUP_GENERIC")) : 0;
   if (a.vol16) {
+    const int m = a.vol16;
+#define VFML_LOOKUP16(RR, OO)                                                                                  \
+  do {                                                                                                          \
+    if (m == 15) hipLaunchKernelGGL((corr_lookup_fixed_kernel<RR, OO, 15>), grid, block, 0, st, a);             \
+    else if (m == 14) hipLaunchKernelGGL((corr_lookup_fixed_kernel<RR, OO, 14>), grid, block, 0, st, a);        \
+    else if (m == 12) hipLaunchKernelGGL((corr_lookup_fixed_kernel<RR, OO, 12>), grid, block, 0, st, a);        \
+    else hipLaunchKernelGGL((corr_lookup_fixed_kernel<RR, OO, 8>), grid, block, 0, st, a);                      \
+  } while (0)
     if (radius == 4) {
-      if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, false, true>), grid, block, 0, st, a);
+      if (a.out16) VFML_LOOKUP16(4, true);
+      else VFML_LOOKUP16(4, false);
     } else {
-      if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, true, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((corr_lookup_fixed_kernel<3, false, true>), grid, block, 0, st, a);
+      if (a.out16) VFML_LOOKUP16(3, true);
+      else VFML_LOOKUP16(3, false);
     }
+#undef VFML_LOOKUP16
   } else if (radius == 4 && !generic && levels <= FIXED_LEVELS) {
     if (a.out16) hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((corr_lookup_fixed_kernel<4, false>), grid, block, 0, st, a);

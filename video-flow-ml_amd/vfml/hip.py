@@ -19,6 +19,16 @@ SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hi
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
 FMT_F32, FMT_S16, FMT_F16 = 0, 1, 2     # storage formats (include/vfml.h; FMT_F16: correlation volumes only)
+
+
+def vol_f16_levels(mask):
+    """vol_fmt of a lookup over pyramids whose levels in `mask` (bit l = level l) hold f16 texels (VFML_VOL_F16_LEVELS)."""
+    return 0x100 | mask
+
+
+def _vol_mask(vol_fmt, levels):
+    return (15 if vol_fmt == FMT_F16 else (vol_fmt & 15 if vol_fmt & 0x100 else 0)) & ((1 << levels) - 1)
+
 KORDER_TAP, KORDER_CBLOCK, KORDER_CBLOCK64 = 0, 1, 2   # K-axis order of split weight planes (include/vfml.h)
 CONV_SWAP_CROSS, CONV_MFMA2, CONV_MFMA1, CONV_MFMA2A, CONV_PER_TAP = 1, 2, 4, 8, 16   # vfml_conv_desc.flags
 
@@ -521,7 +531,9 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
     e1.record()
     # algorithmic bytes: per query and level the (2r+2)^2 integer-grid patch in, (2r+1)^2 samples out
     q = nmaps * q_per_map
-    _PROFILE_HBM.append(("corr_lookup", q * L * ((2 * radius + 2) ** 2 * (2.0 if vol_fmt == FMT_F16 else 4.0) + (2 * radius + 1) ** 2 * 4.0), e0, e1))
+    m16 = _vol_mask(vol_fmt, L)
+    texel_bytes = sum(2.0 if (m16 >> l) & 1 else 4.0 for l in range(L))
+    _PROFILE_HBM.append(("corr_lookup", q * ((2 * radius + 2) ** 2 * texel_bytes + L * (2 * radius + 1) ** 2 * 4.0), e0, e1))
 
 
 class VolTile:

@@ -263,13 +263,15 @@ class MOFNetHIP(_Holder):
         """The arithmetic as part of a cached frame's identity."""
         p = self._precision()
         vol = getattr(self.cfg, "corr_volume", "f32")
-        if vol not in ("f32", "f16"):
-            raise ValueError(f"cfg.corr_volume must be 'f32' or 'f16', got {vol!r}")
+        if vol not in self.CORR_VOLUMES:
+            raise ValueError(f"cfg.corr_volume must be one of {tuple(self.CORR_VOLUMES)}, got {vol!r}")
         key = (p, tuple(sorted((k, str(v)) for k, v in self._mixed_plan().items()))) if p == "mixed" else p
         if self._tile() is None:
             key = (key, "row-major")
         return key if vol == "f32" else (key, vol)
 
+    # cfg.corr_volume -> mask of the pyramid levels stored as one f16 per value (bit l = level l)
+    CORR_VOLUMES = {"f32": 0, "f16": 15, "f16@1": 14, "f16@2": 12, "f16@3": 8}
     _VOL_TILE = hip.VolTile(2, 3)
 
     def _tile(self):
@@ -588,20 +590,28 @@ class MOFNetHIP(_Holder):
         Nl = [VT.count(hl[l], wl[l]) for l in range(L)] if VT is not None else Sl
         Pv = Nl[0]
         TILE = VT.code if VT is not None else 0
-        # cfg.corr_volume 'f16': the pyramids as one f16 per value, written by the GEMM form (which needs every level's
-        # width a multiple of 4 and split-row query features) - other geometries keep f32 volumes
-        vol16 = (getattr(cfg, "corr_volume", "f32") == "f16" and AF == hip.FMT_S16 and Pv % 4 == 0
-                 and all(s % 4 == 0 for s in Nl))
-        VF = hip.FMT_F16 if vol16 else hip.FMT_F32
+        # cfg.corr_volume 'f16' / 'f16@k': the pyramids (from level k up) as one f16 per value, written by the GEMM form
+        # (which needs every level's width a multiple of 4 and split-row query features) - other geometries keep f32
+        # volumes.  The lookup reads as many texels of every level (a (2r+2)^2 window each), so levels 1-3 carry three
+        # quarters of what f16 texels save it, at 13 % of the volume's bytes
+        mask = self.CORR_VOLUMES[getattr(cfg, "corr_volume", "f32")] & ((1 << L) - 1)
+        if not (mask and AF == hip.FMT_S16 and Pv % 4 == 0 and all(s % 4 == 0 for s in Nl) and L <= 4
+                and cfg.corr_radius in (3, 4)):
+            mask = 0
+        v16 = [bool((mask >> l) & 1) for l in range(L)]
+        VFl = [hip.FMT_F16 if v16[l] else hip.FMT_F32 for l in range(L)]
+        VF = (hip.FMT_F32 if not mask else hip.FMT_F16 if mask == (1 << L) - 1 else hip.vol_f16_levels(mask))   # the lookups' vol_fmt
         # row stride of a level: whole 128-byte lines, an ODD number of them - the transposed second output of the
         # level-0 GEMM walks down a column, and at an even multiple (32640 floats = 255 x 512 bytes at 1080p) its
         # stores queue on half the memory channels: 1989 us per launch against 1652 (tools/exp/volume_gemm_shapes.py)
-        unit = 64 if vol16 else 32
-        ldl = [(s + unit - 1) // unit * unit for s in Nl]
-        ldl = [n if (n // unit) % 2 else n + unit for n in ldl]
-        psz = [(Pv * ldl[l] + 1) // 2 if vol16 else Pv * ldl[l] for l in range(L)]     # floats per level buffer
-        return types.SimpleNamespace(L=L, AF=AF, hl=hl, wl=wl, Sl=Sl, VT=VT, Nl=Nl, Pv=Pv, TILE=TILE, vol16=vol16, VF=VF,
-                                     ldl=ldl, psz=psz)
+        ldl = []
+        for l in range(L):
+            unit = 64 if v16[l] else 32
+            n = (Nl[l] + unit - 1) // unit * unit
+            ldl.append(n if (n // unit) % 2 else n + unit)
+        psz = [(Pv * ldl[l] + 1) // 2 if v16[l] else Pv * ldl[l] for l in range(L)]     # floats per level buffer
+        return types.SimpleNamespace(L=L, AF=AF, hl=hl, wl=wl, Sl=Sl, VT=VT, Nl=Nl, Pv=Pv, TILE=TILE, vol16=mask, VF=VF,
+                                     VFl=VFl, ldl=ldl, psz=psz)
 
     def _prefetch_pyramids(self):
         """VFML_PREFETCH_PYR=1: the next window's new correlation pyramids are built on the prefetch stream too.  Off: the
@@ -616,7 +626,7 @@ class MOFNetHIP(_Holder):
         problems.  Returns {"f": [...], "b": [...]} (per centre frame, a list of level buffers).
         protect: cache keys of pyramids another stream is reading - their buffers are not recycled for new ones."""
         D, L = self.cfg.feat_dim, geo.L
-        AF, VF, Nl, Pv, ldl, psz = geo.AF, geo.VF, geo.Nl, geo.Pv, geo.ldl, geo.psz
+        AF, VFl, Nl, Pv, ldl, psz = geo.AF, geo.VFl, geo.Nl, geo.Pv, geo.ldl, geo.psz
         scale = 1.0 / float(D) ** 0.5
         if AF == hip.FMT_S16:
             scale /= self.FMAP_ROW_SCALE       # the split-row query features carry a factor 16
@@ -654,14 +664,14 @@ class MOFNetHIP(_Holder):
                     for l in range(L):
                         # (one MFMA per product is symmetric in its operands: no swapped cross terms to order)
                         hip.conv2d(feats[c][0], D, D, 1, 1, Pv, feats[tgt][1][l], None, Nl[l], 1, 1, pyr[l],
-                                   ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF,
+                                   ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VFl[l],
                                    swap_cross=(d == "b" and l == 0 and gemm_form and cnm == 3),
                                    out_t=rev[0] if dual and l == 0 else None, ld_out_t=ldl[0] if dual and l == 0 else 0,
                                    mfma=cnm)
                     if dual:
                         for l in range(1, L):
                             hip.conv2d(feats[tgt][0], D, D, 1, 1, Pv, feats[c][1][l], None, Nl[l], 1, 1, rev[l],
-                                       ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VF, mfma=cnm)
+                                       ldl[l], out_scale=scale, in_fmt=AF, out_fmt=VFl[l], mfma=cnm)
                 pyrs[d].append(pyr)
         return pyrs
 

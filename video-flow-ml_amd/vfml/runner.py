@@ -82,7 +82,9 @@ class ClipFeeder:
     RING = 4
 
     def __init__(self, frames, device):
-        f0 = frames[0]
+        """frames: list of uint8 [H,W,3] arrays; entries may be None where this process will never need the frame (another
+        rank's stretch of a sharded clip): those are never uploaded, and asking for one raises."""
+        f0 = next(f for f in frames if f is not None)
         self.device = torch.device(device)
         self.clip = torch.empty((len(frames),) + tuple(f0.shape), dtype=torch.uint8, device=self.device)
         self.on_gpu = self.device.type == "cuda"
@@ -97,8 +99,8 @@ class ClipFeeder:
         """Start over with another list of frames of the same shape and count (the buffers are kept; the clip gets
         a new identity, so nothing cached for the old frames is found under the new ones)."""
         from .clip_id import new_id
-        f0 = frames[0]
-        if (any(f.dtype != np.uint8 or f.shape != f0.shape for f in frames) or len(frames) != self.clip.shape[0]
+        f0 = next(f for f in frames if f is not None)
+        if (any(f is not None and (f.dtype != np.uint8 or f.shape != f0.shape) for f in frames) or len(frames) != self.clip.shape[0]
                 or tuple(f0.shape) != tuple(self.clip.shape[1:])):
             raise ValueError("ClipFeeder expects uint8 frames of one shape (and, on reset, the shape it was built for)")
         self.frames = frames
@@ -127,8 +129,17 @@ class ClipFeeder:
             raise RuntimeError(f"ClipFeeder: frame {first} was skipped by an earlier shard of this feeder (frames below "
                                f"{self.lo} were never uploaded); reset() the feeder or build a new one for this job")
 
-    def ensure(self, upto):
+    def ensure(self, upto, need=None):
+        """Upload ahead to frame `upto` (as far as this process holds the frames); `need`: the last frame the caller is
+        about to read - not having that one is an error."""
         upto = min(upto, len(self.frames) - 1)
+        for f in range(self.next, upto + 1):
+            if self.frames[f] is None:          # another rank's stretch: the read-ahead stops here
+                upto = f - 1
+                break
+        if need is not None and min(need, len(self.frames) - 1) > max(upto, self.next - 1):
+            raise RuntimeError(f"ClipFeeder: frame {max(upto, self.next - 1) + 1} is not held by this process (None in its "
+                               f"frame list) but a window reaches frame {need}")
         if upto < self.next:
             return
         if not self.on_gpu:
@@ -335,7 +346,7 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     def feed(first, last):
         if feeder is not None:
             feeder.require(max(0, first - (seq - 1)))       # (VideoFlow windows reach seq // 2 back, MemFlow's seq - 1)
-            feeder.ensure(last + seq)                       # the window's last frame and a few ahead
+            feeder.ensure(last + seq, need=last + seq // 2)  # the window's last frame (VideoFlow: seq // 2 ahead) and a few more
 
     def compute_chunk(c, sbuf):
         part = mine[c * K:(c + 1) * K]

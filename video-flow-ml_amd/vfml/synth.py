@@ -14,15 +14,16 @@ def _texture(rng, h, w, k=9):
     return ((box - lo) / (hi - lo) * 255.0).astype(np.uint8)
 
 
-def synthetic_clip(num_frames, height, width, seed=SEED):
-    """List of `num_frames` uint8 [height,width,3] frames."""
+def synthetic_clip(num_frames, height, width, seed=SEED, start=0):
+    """List of `num_frames` uint8 [height,width,3] frames: frames start .. start + num_frames - 1 of the clip (frame t
+    depends on t alone, so a rank of a sharded job can generate its own stretch only)."""
     margin = 128
     bg = _texture(np.random.default_rng(seed), height + 2 * margin, width + 2 * margin)
     fg = _texture(np.random.default_rng(seed + 1), height, width)
     yy, xx = np.mgrid[0:height, 0:width]
     rad = height / 6.0
     frames = []
-    for t in range(num_frames):
+    for t in range(start, start + num_frames):
         oy = margin + int(round(-0.75 * (t % 120)))   # periodic so long clips stay inside the margin
         ox = margin + int(round(1.5 * (t % 60))) - 45
         f = bg[oy:oy + height, ox:ox + width].copy()
