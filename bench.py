@@ -49,7 +49,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3
 DTYPE_NOTE = {
     "f16x3": "f16x3 (split-f16 MFMA: 3 f16 MFMAs per product, f32 accumulate, fp32-grade)",
     "f16x2": "f16x2 (weights as plain f16: 2 f16 MFMAs per product, f32 accumulate)",
-    "f16": "f16 (plain f16 MFMA operands, f32 accumulate)",
+    "f16": "f16 (plain f16 MFMA operands, f32 accumulate; at 720p 2.1e-3 px mean EPE vs the fp32 oracle: outside the 1e-3 contract)",
     "f32": "f32",
 }
 
@@ -66,8 +66,9 @@ def main():
                     help="mof1080p = BASELINE.json configs[1] (the headline, default); the others are the remaining "
                          "GPU configs, measured with the same protocol for DESIGN.md (not the driver's line)")
     ap.add_argument("--precision", default=None, choices=["f16x3", "f16x2", "f16", "mixed", "f32"],
-                    help="arithmetic of the engine (vfml/cfg.py); default: f16x3, and f16 for bof720p (BASELINE config 5 "
-                         "is quoted in fp16)")
+                    help="arithmetic of the engine (vfml/cfg.py); default: the mixed plan (mof1080p: DEFAULT_MIXED_PLAN, "
+                         "1e-4-grade; bof720p: BOF_F16_PLAN, BASELINE config 5's fp16 inside the 1e-3 px contract - the "
+                         "line then carries plain 'f16' everywhere beside it)")
     ap.add_argument("--corr-volume", default=None, choices=["f32", "f16", "f16@1", "f16@2", "f16@3"],
                     help="storage of the correlation pyramids (vfml/cfg.py corr_volume; default f32; f16 is the opt-in "
                          "half-size volume, ~1e-4 px against the oracle at 1080p)")
@@ -101,9 +102,11 @@ def main():
     # mof1080p runs the EPE-budgeted mixed plan by default (vfml/cfg.py DEFAULT_MIXED_PLAN: mean EPE <= 1e-4 px at
     # 1080p on three weight seeds and T in {3, 5}, tests/test_gpu_e2e.py) and reports the fp32-grade all-3 arithmetic
     # ('f16x3') beside it as `plans`; --precision f16x3 makes that the headline instead
-    precision = args.precision or {"bof720p": "f16", "mof1080p": "mixed"}.get(args.workload)
+    precision = args.precision or {"bof720p": "mixed", "mof1080p": "mixed"}.get(args.workload)
     if precision and args.workload != "memflow1080p":
         os.environ["VFML_PRECISION"] = precision  # read by VideoFlowCore
+        if args.workload == "bof720p" and precision == "mixed":
+            os.environ.setdefault("VFML_MFMA_PLAN", "bof-f16")
     if args.corr_volume:
         os.environ["VFML_CORR_VOLUME"] = args.corr_volume
     from vfml import dist as vdist, get_cfg, hip
@@ -154,7 +157,8 @@ def main():
     K, Wm, T = args.steps, args.warmup, args.seq
     Pn = 0 if args.no_roofline else min(K, 4)
     En = min(K, 6)
-    alt_precision = "f16x3" if (args.workload == "mof1080p" and precision == "mixed" and world == 1) else None
+    alt_precision = ({"mof1080p": "f16x3", "bof720p": "f16"}.get(args.workload)
+                     if (precision == "mixed" and world == 1) else None)
     An = (Wm + K + Wm) if alt_precision else 0           # second plan: warm-up + timed, then the first plan's warm-up again
     per_rank = Wm + K + En + An + Pn
     # the job is one clip of world * per_rank fields; every rank holds it in host memory (same synthetic generator on
@@ -223,6 +227,7 @@ def main():
     # -- the other arithmetic plan on the next fields of the same job (N = 1 only): its own warm-up, then K timed fields
     alt = None
     if alt_precision:
+        first_plan = dict(core.cfg.mfma_plan or {})
         core.cfg.precision, core.cfg.mfma_plan = alt_precision, None
         core.model.clear_feature_cache()      # nothing of the first plan's cached frames / pyramids is of use to this one
         torch.cuda.synchronize()
@@ -237,8 +242,7 @@ def main():
         del out
         core.cfg.precision = precision
         if precision == "mixed":
-            from vfml.cfg import DEFAULT_MIXED_PLAN
-            core.cfg.mfma_plan = dict(DEFAULT_MIXED_PLAN)
+            core.cfg.mfma_plan = dict(first_plan)
         core.model.clear_feature_cache()
         job(mine[base + Wm + K:base + Wm + K + Wm], collect=False)     # back in the headline plan's steady state
         torch.cuda.synchronize()
@@ -311,8 +315,11 @@ def main():
     if alt is not None:
         result["plans"] = {
             prec: {"value": total_fields / elapsed, "ms_per_step": 1000.0 * elapsed / K, "dtype": dtype,
-                   "epe_budget": "mean EPE <= 1e-4 px vs the fp32 oracle at 1080p (3 weight seeds, T in {3, 5}): "
-                                 "tests/test_gpu_e2e.py::test_mixed_plan_stays_within_its_budget_at_1080p"},
+                   "epe_budget": ("mean EPE <= 1e-4 px vs the fp32 oracle at 1080p (3 weight seeds, T in {3, 5}): "
+                                  "tests/test_gpu_e2e.py::test_mixed_plan_stays_within_its_budget_at_1080p"
+                                  if args.workload == "mof1080p" else
+                                  "mean EPE < 5e-4 px vs the fp32 oracle at 720p seq 9 (vfml/cfg.py BOF_F16_PLAN: "
+                                  "tests/test_gpu_e2e.py::test_bof_720p_seq9_fp16_config)")},
             alt_precision: {"value": K / alt, "ms_per_step": 1000.0 * alt / K, "dtype": DTYPE_NOTE[alt_precision],
                             "note": "same job and protocol, the next fields of the clip, after its own warm-up"},
         }

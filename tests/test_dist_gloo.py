@@ -317,3 +317,21 @@ def test_world8_rank0_host_work_stays_below_compute_time():
           f"unpack thread {unp[len(unp) // 2]:.1f} ms for {world * 2 * 16.6:.0f} MB")
     assert hand[len(hand) // 2] < 0.1 * chunk_ms
     assert unp[len(unp) // 2] < chunk_ms
+
+
+def test_feeder_over_a_clip_of_which_this_process_holds_one_stretch():
+    """bench.py --gpus N: a rank generates only its own stretch of the synthetic clip; the other entries of its frame list
+    are None, never uploaded, and the read-ahead stops in front of them - but a window that NEEDS one raises."""
+    from vfml.runner import ClipFeeder, run_sharded
+    proc = _proc(False)
+    frames = _clip(16)
+    mine = [None] * 16
+    mine[4:12] = frames[4:12]                   # fields 6..9 have their whole 5-frame windows in 4..11
+    feeder = ClipFeeder(mine, "cpu")
+    got = run_sharded(proc, None, [6, 7, 8, 9], feeder=feeder)
+    ser = _proc(False)
+    for k, i in enumerate((6, 7, 8, 9)):
+        assert np.array_equal(got[k], ser.compute_optical_flow(frames, i)), i
+    assert feeder.lo == 4 and feeder.next == 12                             # nothing of the other stretches was touched
+    with pytest.raises(RuntimeError, match="not held by this process"):
+        run_sharded(proc, None, [10], feeder=feeder)                          # its window reaches frame 12

@@ -30,12 +30,16 @@ class VideoFlowCore:
         # 'mixed' VFML_MFMA_PLAN = JSON {layer prefix: 1|2|"2a"|3}.  Unset: 'mixed' with the shipped per-layer plan for the
         # multi-frame network - the arithmetic bench.py's headline is measured in, held to mean EPE <= 1e-4 px against the
         # fp32 oracle at 1080p by tests/test_gpu_e2e.py (a tenth of the drop-in's 1e-3 px contract; upstream itself runs
-        # autocast f16) - and the fp32-grade 'f16x3' for the tri-frame network, whose plan is measured separately.
-        self.precision = os.environ.get("VFML_PRECISION") or ("mixed" if self.architecture == "mof" else None)
+        # autocast f16); the same plan for the tri-frame network (4.5e-5 px against its all-3 field at 720p seq 9).
+        # VFML_MFMA_PLAN may also NAME a shipped plan (vfml/cfg.py NAMED_PLANS): "bof-f16" is BASELINE config 5's fp16-grade
+        # arithmetic (2e-4 px at 720p, inside the 1e-3 contract - which plain 'f16' everywhere is not).
+        self.precision = os.environ.get("VFML_PRECISION") or "mixed"
         self.mfma_plan = None
         if os.environ.get("VFML_MFMA_PLAN"):
             import json
-            self.mfma_plan = json.loads(os.environ["VFML_MFMA_PLAN"])
+            from vfml.cfg import NAMED_PLANS
+            spec = os.environ["VFML_MFMA_PLAN"]
+            self.mfma_plan = dict(NAMED_PLANS[spec]) if spec in NAMED_PLANS else json.loads(spec)
 
     # -- model ------------------------------------------------------------------------------
     def load_model(self):

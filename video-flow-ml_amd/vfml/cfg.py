@@ -40,6 +40,24 @@ DEFAULT_MIXED_PLAN = {
     "update_block.gru.convq1.iter": "2a",
     "update_block.tprop": "2a",
 }
+# BASELINE config 5 ("BOF_things seq_len=9 1280x720 fp16"): an fp16-GRADE plan that stays inside the drop-in's 1e-3 px contract,
+# which plain f16 everywhere does not (2.1e-3 px mean EPE against the fp32 oracle at 720p).  One MFMA per product ("": 1)
+# wherever a WEIGHT's rounding does not reach the flow linearly; what runs once per frame keeps all three terms (the context
+# encoder alone costs 1.3e-3 px at one term, the feature encoder and the context parts of the gates 1.5e-4); the layers on
+# the linear flow path - motion-encoder output and second correlation layer, both flow-head layers - take their ACTIVATIONS
+# as plain f16 and keep the weights' lo half ("2a").  Measured at 1280x720 seq 9 (tools/precision_plan.py --arch bof
+# --candidates, gpurun_out/r03_bofplan.log): 2.1e-4 px against the all-3 field at 9.15 ms per field in the sliding state
+# (all-1: 2.1e-3 px, 8.23 ms; all-3: 10.47 ms; the 1e-4-grade DEFAULT_MIXED_PLAN: 4.5e-5 px, 9.63 ms).
+_UB = "update_block"
+BOF_F16_PLAN = {
+    "": 1,
+    "cnet": 3, "fnet": 3,
+    f"{_UB}.gru.convzr1.ctx": 3, f"{_UB}.gru.convq1.ctx": 3, f"{_UB}.gru.convzr2.ctx": 3, f"{_UB}.gru.convq2.ctx": 3,
+    f"{_UB}.encoder.conv": "2a", f"{_UB}.encoder.convc2": "2a",
+    f"{_UB}.flow_head.conv1": "2a", f"{_UB}.flow_head.conv2": "2a",
+}
+NAMED_PLANS = {"default": DEFAULT_MIXED_PLAN, "bof-f16": BOF_F16_PLAN}     # VFML_MFMA_PLAN may name one
+
 # (A/B switch: VFML_PLAN_EXCLUDE="layer,layer" takes entries out of the default plan - those layers run all three terms)
 for _k in filter(None, os.environ.get("VFML_PLAN_EXCLUDE", "").split(",")):
     DEFAULT_MIXED_PLAN.pop(_k, None)

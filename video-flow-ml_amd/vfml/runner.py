@@ -133,6 +133,8 @@ class ClipFeeder:
         """Upload ahead to frame `upto` (as far as this process holds the frames); `need`: the last frame the caller is
         about to read - not having that one is an error."""
         upto = min(upto, len(self.frames) - 1)
+        while self.next == self.lo and self.next <= upto and self.frames[self.next] is None:
+            self.lo = self.next = self.next + 1         # (leading frames this process does not hold: skipped like skip_to's)
         for f in range(self.next, upto + 1):
             if self.frames[f] is None:          # another rank's stretch: the read-ahead stops here
                 upto = f - 1
@@ -343,10 +345,20 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     if feeder is not None and mine:
         feeder.skip_to(min(f for f, _ in mine) - seq)       # (a window reaches at most seq - 1 frames back)
 
+    def window(f):
+        """Frames the processor reads for field f (VideoFlow: centred, seq // 2 either side; MemFlow: the seq - 1 before it)."""
+        wi = getattr(proc, "window_indices", None)
+        if wi is None:
+            return [max(0, f - (seq - 1)), min(F - 1, f + seq // 2)]
+        try:
+            return wi(F, f)
+        except TypeError:
+            return wi(f)
+
     def feed(first, last):
         if feeder is not None:
-            feeder.require(max(0, first - (seq - 1)))       # (VideoFlow windows reach seq // 2 back, MemFlow's seq - 1)
-            feeder.ensure(last + seq, need=last + seq // 2)  # the window's last frame (VideoFlow: seq // 2 ahead) and a few more
+            feeder.require(min(window(first)))
+            feeder.ensure(last + seq, need=max(window(last)))   # the window's last frame, and a few more ahead of use
 
     def compute_chunk(c, sbuf):
         part = mine[c * K:(c + 1) * K]
