@@ -411,7 +411,7 @@ def test_bof_720p_seq9_fp16_config(gpu):
     centre triple of the 9-frame window, (a) in the fp32-grade arithmetic (f16x3) within the 1e-3 px tolerance of the
     CPU oracle, (b) in the config's fp16-GRADE plan (vfml/cfg.py BOF_F16_PLAN: one MFMA per product except the per-frame
     encoders / context parts at three and the linear flow path at "2a") INSIDE that tolerance with margin - < 5e-4 px, about
-    twice what it measures (2.1e-4) - on three weight seeds (seed 0 against the CPU oracle, seeds 1-2 against the f16x3
+    twice what it measures (1.5e-4 .. 2.1e-4) - on three weight seeds (seed 0 against the CPU oracle, seeds 1-2 against the f16x3
     engine, itself ~6e-6 px from the oracle), (c) in 'f16' (plain f16 operands everywhere): 2.1e-3 px, OUTSIDE the
     contract by design - reported and bounded at twice its measured value so that a broken kernel, not a rounding, fails,
     (d) the job loop's batched evaluation (eight fields per pass, tri_batch) bit-identical to one field per call at this

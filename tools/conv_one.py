@@ -10,9 +10,10 @@ x = torch.randn(n * h * w * ld, device="cuda")
 wt = torch.randn(cout * kh * kw * cin, device="cuda") / math.sqrt(cin * kh * kw)
 b = torch.randn(cout, device="cuda")
 from vfml.weights import pack_conv_weight
-wc = pack_conv_weight(wt.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2), cblock=True)
+mfma = int(os.environ.get("MB_MFMA", "3"))          # 1: one MFMA per product over 64-channel steps (the gate layers of the mixed plan)
+wc = pack_conv_weight(wt.reshape(cout, kh, kw, cin).permute(0, 3, 1, 2), cblock=64 if mfma == 1 else True)
 wobj = hip.SplitWeight(cout, wc.numel() // cout, x.device).fill(wc, scale=hip.SplitWeight.auto_scale(float(wt.abs().max())))
-wobj.order = hip.KORDER_CBLOCK
+wobj.order = hip.KORDER_CBLOCK64 if mfma == 1 else hip.KORDER_CBLOCK
 out = torch.empty(n * h * w * cout, device="cuda")
 fmt = hip.FMT_S16 if os.environ.get("S16", "1") == "1" else hip.FMT_F32
 if fmt == hip.FMT_S16:
@@ -21,5 +22,5 @@ if fmt == hip.FMT_S16:
     x = x16
 for _ in range(5):
     hip.conv2d(x, cin, ld, n, h, w, wobj, b, cout, kh, kw, out, cout, pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU,
-               in_fmt=fmt, out_fmt=fmt)
+               in_fmt=fmt, out_fmt=fmt, mfma=mfma)
 torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a wave's cycles go in conv_gemm_tapx_kernel (experiment build, GPU only): rebuilds conv_gemm_tapx.hip with
--DVFML_TAPX_STAMPS into tools/exp/libvfml_stamps.so (the other objects are the shipped ones), runs one 1080p update-block
+`-include tools/exp/tapx_hooks.h` (the in-kernel stamps live there, not in the product source) into tools/exp/libvfml_stamps.so (the other objects are the shipped ones), runs one 1080p update-block
 shape and prints, per wave of one mid-grid workgroup, the mean cycles per K step spent (X) reading the weight fragments
 and waiting at the barrier that frees the weight stage, (M) in the MFMA phase (LDS-DMA issues included), (W) waiting for
 the step's pieces (vmcnt), (Y) at the barrier that closes the step.
@@ -19,7 +19,8 @@ LIB = os.path.join(ROOT, "tools", "exp", f"libvfml_stamps{TAG}.so")
 
 def build():
     obj = os.path.join(ROOT, "tools", "exp", f"tapx_stamps{TAG}.o")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DVFML_TAPX_STAMPS"] + [f for f in sys.argv if f.startswith("-D")] + ["-c",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-include",
+                    os.path.join(ROOT, "tools", "exp", "tapx_hooks.h")] + [f for f in sys.argv if f.startswith("-D")] + ["-c",
                     os.path.join(CSRC, "conv_gemm_tapx.hip"), "-o", obj], check=True)
     others = [os.path.join(CSRC, "_obj", f) for f in sorted(os.listdir(os.path.join(CSRC, "_obj")))
               if f.endswith(".o") and not f.startswith("conv_gemm_tapx")]

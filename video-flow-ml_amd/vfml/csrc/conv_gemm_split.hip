@@ -267,29 +267,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_split_kernel(const 
   load_tile(st1, BK);
   store_tile(st0, 0);
   __syncthreads();
-  // -DVFML_EXPERIMENT_NOLOAD builds a timing-only variant without the in-loop loads and LDS writes
-  // (garbage results): the MFMA + fragment-read phase alone runs at 500-570 TFLOP/s algorithmic vs
-  // 285-310 with staging (tools/conv_microbench.py; DESIGN.md "what bounds the conv kernel").
+  // (round 1, timing only: without the in-loop loads and LDS writes the MFMA + fragment-read phase alone ran at 500-570
+  // TFLOP/s algorithmic against 285-310 with staging - profiles/HISTORY.md "what bounds the conv kernel")
   for (int kt = 0; kt < nk; kt += 2) {
-#ifndef VFML_EXPERIMENT_NOLOAD
     load_tile(st0, (kt + 2) * BK);
-#endif
     __builtin_amdgcn_sched_barrier(0);   // loads first ...
     compute(0);
     __builtin_amdgcn_sched_barrier(0);   // ... their consumers (split + LDS write) only after the MFMAs
-#ifndef VFML_EXPERIMENT_NOLOAD
     store_tile(st1, 1);
-#endif
     __syncthreads();
-#ifndef VFML_EXPERIMENT_NOLOAD
     load_tile(st1, (kt + 3) * BK);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     compute(1);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef VFML_EXPERIMENT_NOLOAD
     store_tile(st0, 0);
-#endif
     __syncthreads();
   }
 
@@ -420,12 +411,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   int scb = 0, sky = 0, skx = 0;   // uniform-step loader: channel block and tap of the step (scalars)
   int m0, n0;
   int ks = 0;          // a.ksplit == 2: the half of the K axis this work item covers
-#ifdef VFML_EXPERIMENT_ZERODESC   // timing only: every DMA is range-checked away, the instruction stream stays
-  __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, 0, 0x00020000);
-#else
   __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(const_cast<float*>(a.in0)) - a.abias, 0, a.bytes0 + a.abias, 0x00020000);
-#endif
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
 
   // steps per work item (rounded up to even; a second half that reaches past K reads zeros on the source side)
@@ -584,9 +571,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
     }
   };
   auto issue_piece = [&](int stg, int pc) {
-#ifdef VFML_EXPERIMENT_NOLOAD
-    return;
-#endif
     if (pc < AP)
       dma16(r0, va[pc < AP ? pc : 0], soffA, smem_raw + stg * STG + wave * (8 * 128) + pc * (8 * NW * 128));
     else if (pc < AP + BP)
@@ -644,10 +628,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc4[i][j], 0, 0, 0);
             if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, acc4[i][j], 0, 0, 0);
             if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, acc4[i][j], 0, 0, 0);
-#ifndef VFML_ISSUE_DIV
-#define VFML_ISSUE_DIV 2      // the next step's pieces go out behind the first 1/DIV of this step's MFMA groups
-#endif
-            constexpr int GROUPS4 = KS * 4 * TM * TN / VFML_ISSUE_DIV;
+            // the next step's pieces go out behind the first HALF of this step's MFMA groups (behind a quarter, or all of
+            // them: +-1 %, round 2)
+            constexpr int GROUPS4 = KS * 4 * TM * TN / 2;
             constexpr int g = (ks * 2 * TM + i) * (2 * TN) + j;
             constexpr int PER4 = (AP + BP + GROUPS4 - 1) / GROUPS4;
             if constexpr (g < GROUPS4) {
@@ -709,15 +692,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           } else {
-#ifndef VFML_EXPERIMENT_2MFMA     // timing / accuracy experiment: second operand (weights) as plain f16
             if constexpr (!BHI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#endif
             if constexpr (!AHI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
           }
-#ifndef VFML_ISSUE_GROUPS
-#define VFML_ISSUE_GROUPS (TM * TN)      // the first half of the step: the second half covers the pieces' L2 latency
-#endif
-          constexpr int GROUPS = VFML_ISSUE_GROUPS;
+          constexpr int GROUPS = TM * TN;      // the first half of the step: the second half covers the pieces' L2 latency
           const int g = (ks * TM + i) * TN + j;
           // spread AP+BP pieces over the first GROUPS groups (the first groups get one more when it does not divide)
           constexpr int PER = (AP + BP + GROUPS - 1) / GROUPS;
@@ -798,18 +776,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
     for (int kt = 0; kt < nk - 2; kt += 2) step_pair(kt, false, next);
     step_pair(nk - 2, true, next);
 
-#ifdef VFML_EXPERIMENT_NOSTORE   // timing only: no epilogue at all (accumulators kept alive)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::"v"(acc[i][j]));
-#endif
-      }
-    if (true) {
-    } else
-#endif
     if constexpr (PERSIST) {
       // Wide plain-f32 outputs (the correlation GEMM: K is short, the tile's 4 bytes per product dominate).
       // Each wave transposes its own 32*TM x 32*TN block through a private 32 x 32*TN slab in stage 1
@@ -822,6 +788,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       const int cols_valid = a.cout - cur_n0 < TBN ? a.cout - cur_n0 : TBN;
       // (out_h16: VFML_FMT_F16 outputs - one f16 per element, 8-byte stores of four; same store count, half the bytes)
       constexpr int ES = H16 ? 2 : 4;
+      constexpr int STORE_NT = 2;            // buffer-store aux bits: nt - the volume is streamed out once
       // (ksplit: the second half's partial sums go to the workspace; the host adds them after the launch)
       char* tbase = reinterpret_cast<char*>(cur_ks ? a.out_k1 : a.out) + ((int64_t)cur_m0 * a.ldo + cur_n0) * ES;
       const __amdgpu_buffer_rsrc_t ro =
@@ -865,16 +832,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             if (a.epilogue == VFML_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
           }
           const int roff = (i * 32 + p * RPI) * a.ldo * ES;
-#ifndef VFML_STORE_AUX
-#define VFML_STORE_AUX 2      // nt: the volume is streamed out once
-#endif
           if constexpr (H16) {
             const h16x2 p0 = {(_Float16)v[0], (_Float16)v[1]}, p1 = {(_Float16)v[2], (_Float16)v[3]};
             const u32x2 hv = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
-            __builtin_amdgcn_raw_buffer_store_b64(hv, ro, gcol < cols_valid ? lbase + roff : OOB, 0, VFML_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(hv, ro, gcol < cols_valid ? lbase + roff : OOB, 0, STORE_NT);
           } else {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, gcol < cols_valid ? lbase + roff : OOB, 0,
-                                                   VFML_STORE_AUX);
+                                                   STORE_NT);
           }
         }
         if constexpr (PERSIST && TN == 2 && FASTK) if (a.out_t) {   // (the general-loader instantiation would spill)
@@ -922,10 +886,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             if constexpr (H16) {
               const h16x2 p0 = {(_Float16)v[0], (_Float16)v[1]}, p1 = {(_Float16)v[2], (_Float16)v[3]};
               const u32x2 hv = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
-              __builtin_amdgcn_raw_buffer_store_b64(hv, rt, ok ? (trow * a.ld_out_t + q0) * 2 : OOB, 0, VFML_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(hv, rt, ok ? (trow * a.ld_out_t + q0) * 2 : OOB, 0, STORE_NT);
             } else {
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rt,
-                                                     ok ? (trow * a.ld_out_t + q0) * 4 : OOB, 0, VFML_STORE_AUX);
+                                                     ok ? (trow * a.ld_out_t + q0) * 4 : OOB, 0, STORE_NT);
             }
           }
         }
@@ -995,209 +959,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
   }
 }
 
-#ifdef VFML_EXPERIMENT_LW
-// ---- loader-wave variant of the convolution form (EXPERIMENT, not built by default) ------------------------------
-// Measured on the 1080p update-block shapes (profiles/r02_loader_wave.md): correct (the split-row kernel tests pass with
-// VFML_LW=1) and 30 % SLOWER than the kernel above (262 vs 377 TFLOP/s on the 1x5 gate convolution): one wave issues an
-// LDS-DMA piece per ~137 cycles, so the 40 pieces of a 192 x 128 step take 5500 cycles where the four MFMA waves issuing
-// ten each, in parallel, take ~1000.  A loader needs as many waves as the consumers it feeds (cf. the ring-gemm row of
-// MI355X_MICROARCH.md: 4 loader + 4 consumer waves), which the register budget of two workgroups per CU does not have.
-// The kernel above lets every MFMA wave issue its share of the K step's LDS-DMA pieces between its MFMAs; a wave issues
-// in order and every piece (M0 move, address VALU, the texture-path hand-off) holds it 40-100 cycles during which its
-// matrix pipe slot goes to the other resident workgroup or to nobody.  Here the WM*WN MFMA waves never touch VMEM in the
-// K loop: a fifth wave of the workgroup owns ALL pieces of a step (TBM/8 + TBN/8), computes their offsets (uniform-step
-// loader: one scalar tap / channel offset per step), issues them into the stage the MFMA waves left one step ago,
-// waits for them (vmcnt) and meets the MFMA waves at ONE barrier per K step:
-//     loader:  issue(0) | wait, barrier_0, issue(1) | wait, barrier_1, issue(2) | ...
-//     MFMA  :           |       barrier_0, compute(0) |     barrier_1, compute(1) | ...
-// barrier_k orders (a) step k's data before its readers and (b) the readers of step k-1 before the refill of their stage.
-// Two stages, two workgroups per CU (10 waves: three on two of the SIMDs, hence the 168-register bound).
-// 16x16x32 MFMAs and the uniform-step loader only (every update-block convolution qualifies).
-template <int TM, int TN, int WM, int WN, int NM>
-__global__ __launch_bounds__((WM * WN + 1) * 64, 3) void conv_gemm_lw_kernel(const SplitArgs a) {
-  constexpr int NW = WM * WN, NT = NW * 64;
-  constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
-  constexpr int APT = TBM / 8, BPT = TBN / 8;
-  constexpr int ASZ = TBM * 128, BSZ = TBN * 128, STG = ASZ + BSZ;
-  constexpr int LDC = TBN + 4;
-  constexpr bool BHI = NM == 2 || NM == 1, AHI = NM == 4 || NM == 1;
-
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sC = reinterpret_cast<float*>(smem_raw);
-
-  const int total = a.mtiles * a.ntiles;
-  int tile;
-  {
-    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
-    const int q = total >> 3, r = total & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + lw;
-  }
-  const int nt = tile % a.ntiles, mt = tile / a.ntiles;
-  const int m0 = mt * TBM, n0 = nt * TBN;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int nk = a.Kp / BK;
-
-  if (wave == NW) {
-    // ------------------------------------------------------------------------------------------- the loader
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(const_cast<float*>(a.in0)) - a.abias, 0, a.bytes0 + a.abias, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wbase), 0, a.bytesb, 0x00020000);
-    // piece pc covers tile rows 8 pc .. 8 pc + 7; lane -> (row lane >> 3, slot lane & 7); the slot holds logical piece
-    // slot ^ swz16((row >> 1) & 7), (row >> 1) & 7 = (4 pc + (lane >> 4)) & 7: two cases, pc even / odd
-    const int pce = (lane & 7) ^ swz16((lane >> 4) & 7), pco = (lane & 7) ^ swz16((4 + (lane >> 4)) & 7);
-    int rpa[APT];
-    unsigned tapbad[APT];          // bit (ky * kw + kx) set: that tap of the row lies outside the image (or row >= M)
-#pragma unroll
-    for (int pc = 0; pc < APT; ++pc) {
-      const int piece = (pc & 1) ? pco : pce;
-      const int kg = piece >> 1, hl = piece & 1;
-      const int m = m0 + 8 * pc + (lane >> 3);
-      unsigned ok = 0u;
-      int off = 0;
-      if (a.pointwise) {
-        if (m < a.M) {
-          ok = 1u;
-          off = (m * a.ld0 + a.d0off) * 4;
-        }
-      } else if (m < a.M) {
-        const int hw = a.ho * a.wo;
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int oy = rem / a.wo;
-        const int ox = rem - oy * a.wo;
-        const int iy0 = oy * a.stride - a.pad_h, ix0 = ox * a.stride - a.pad_w;
-        off = (((n * a.H + iy0) * a.W + ix0) * a.ld0 + a.d0off) * 4;
-        for (int ky = 0; ky < a.kh; ++ky)
-          for (int kx = 0; kx < a.kw; ++kx)
-            if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W) ok |= 1u << (ky * a.kw + kx);
-      }
-      rpa[pc] = off + a.abias + kg * 32 + hl * 16;
-      if (AHI && hl) rpa[pc] |= (int)0x80000000;          // lo slots of the activations: never fetched
-      tapbad[pc] = ~ok;
-    }
-    int cbs[BPT];
-#pragma unroll
-    for (int pc = 0; pc < BPT; ++pc) {
-      const int piece = (pc & 1) ? pco : pce;
-      const int kg = piece >> 1, hl = piece & 1;
-      const int col = n0 + 8 * pc + (lane >> 3);
-      cbs[pc] = col < a.cout && !(BHI && hl) ? (hl ? a.wlo_off : a.whi_off) + col * a.Kp * 2 + kg * 16 : 0x40000000;
-    }
-    int scb = 0, sky = 0, skx = 0;
-    auto issue_step = [&](int k) {
-      char* stage = smem_raw + (k & 1) * STG;
-      const int cl = scb < a.c0 ? scb : scb - a.c0;
-      const int soffA = ((sky * a.W + skx) * a.ld0 + cl) * 4 + (scb < a.c0 ? 0 : a.src1_delta);
-      const unsigned stap = sky * a.kw + skx;
-      const int past = scb >= a.ctot ? (int)0x80000000 : 0;
-      const int soffB = k * (BK * 2);
-#pragma unroll
-      for (int pc = 0; pc < APT; ++pc) {
-        const int bad = __builtin_amdgcn_sbfe((int)tapbad[pc], stap, 1u);     // -1: outside
-        dma16(r0, (bad & (int)0x80000000) | past | rpa[pc], soffA, stage + pc * 1024);
-      }
-#pragma unroll
-      for (int pc = 0; pc < BPT; ++pc) dma16(rb, cbs[pc], soffB, stage + ASZ + pc * 1024);
-      if (++skx == a.kw) {
-        skx = 0;
-        if (++sky == a.kh) {
-          sky = 0;
-          scb += BK;
-        }
-      }
-    };
-    issue_step(0);
-    for (int k = 0; k < nk; ++k) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (k + 1 < nk) issue_step(k + 1);
-    }
-    // the epilogue's barriers (two per slab)
-#pragma unroll
-    for (int i = 0; i < 2 * TM; ++i) __builtin_amdgcn_s_barrier();
-    return;
-  }
-
-  // ---------------------------------------------------------------------------------------------- the MFMA waves
-  const int wm = wave / WN;
-  const int wn = wave - wm * WN;
-  const int r4 = lane & 15, u4 = lane >> 4;
-  const int p16 = (H64 ? (u4 ^ ((r4 >> 1) & 7)) : ((2 * u4) ^ swz16((r4 >> 1) & 7))) * 16;
-  const int aoff4 = (wm * (32 * TM) + r4) * 128 + p16;
-  const int boff4 = ASZ + (wn * (32 * TN) + r4) * 128 + p16;
-  f32x4 acc4[2 * TM][2 * TN];
-  static_for<2 * TM>([&](auto ic) {
-    static_for<2 * TN>([&](auto jc) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc4[decltype(ic)::value][decltype(jc)::value][e] = 0.f;
-    });
-  });
-  for (int k = 0; k < nk; ++k) {
-    __builtin_amdgcn_s_barrier();
-    const char* base = smem_raw + (k & 1) * STG;
-    h16x8 bh[2 * TN], bl[2 * TN];
-#pragma unroll
-    for (int j = 0; j < 2 * TN; ++j) {
-      bh[j] = *reinterpret_cast<const h16x8*>(base + boff4 + j * 2048);
-      if constexpr (!BHI) bl[j] = *reinterpret_cast<const h16x8*>(base + (boff4 ^ 16) + j * 2048);
-    }
-    static_for<2 * TM>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      h16x8 ah, al;
-      ah = *reinterpret_cast<const h16x8*>(base + aoff4 + i * 2048);
-      if constexpr (!AHI) al = *reinterpret_cast<const h16x8*>(base + (aoff4 ^ 16) + i * 2048);
-      static_for<2 * TN>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc4[i][j], 0, 0, 0);
-        if constexpr (!BHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc4[i][j], 0, 0, 0);
-        if constexpr (!AHI) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc4[i][j], 0, 0, 0);
-      });
-    });
-  }
-  // epilogue in TM slabs, as in the kernel above
-  static_for<TM>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    __builtin_amdgcn_s_barrier();       // every wave is done with the stage buffers / with the previous slab
-    static_for<2>([&](auto tc) {
-      constexpr int t2 = decltype(tc)::value;
-      static_for<2 * TN>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          sC[(wm * 32 + t2 * 16 + 4 * u4 + e) * LDC + wn * (32 * TN) + j * 16 + r4] = acc4[2 * i + t2][j][e];
-      });
-    });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (!epilogue_rows_fast<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32))
-      epilogue_rows<TBN, NT>(a, sC, m0, n0, t, WM * 32, 32 * TM, i * 32);
-  });
-}
-
-template <int TM, int TN, int WM, int WN, int NM>
-int launch_lw_k(SplitArgs& a, hipStream_t s) {
-  constexpr int TBM = 32 * TM * WM, TBN = 32 * TN * WN;
-  constexpr size_t stage = 2 * (size_t)(TBM + TBN) * 128;
-  constexpr size_t slab = (size_t)WM * 32 * (TBN + 4) * 4;
-  constexpr size_t lds = stage > slab ? stage : slab;
-  a.mtiles = (a.M + TBM - 1) / TBM;
-  a.ntiles = (a.cout + TBN - 1) / TBN;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_lw_kernel<TM, TN, WM, WN, NM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      vfml_set_error("vfml_conv2d_split: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return 2;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((conv_gemm_lw_kernel<TM, TN, WM, WN, NM>), dim3(a.mtiles * a.ntiles), dim3((WM * WN + 1) * 64), lds, s, a);
-  return vfml_check_launch("vfml_conv2d_split");
-}
-
-#endif  // VFML_EXPERIMENT_LW
 
 template <int TM, int TN, int WM, int WN, bool PERSIST, bool FASTK, bool CSWAP = false, int NM = 3, bool MF16 = false, bool H16 = false>
 int launch_dma_k(SplitArgs& a, hipStream_t s) {
@@ -1255,15 +1016,6 @@ int launch_dma(SplitArgs& a, hipStream_t s) {
     // 1080p update-block shapes: the chip holds a higher clock on it)
     static const int mf32 = getenv("VFML_MF32") ? atoi(getenv("VFML_MF32")) : 0;
     if constexpr (TM * TN >= 2) {
-#ifdef VFML_EXPERIMENT_LW
-      static const int lwave = getenv("VFML_LW") ? atoi(getenv("VFML_LW")) : 0;   // experiment: the loader-wave kernel
-      if (a.fastk && lwave) {
-        if (a.nm == 2) return launch_lw_k<TM, TN, WM, WN, 2>(a, s);
-        if (a.nm == 4) return launch_lw_k<TM, TN, WM, WN, 4>(a, s);
-        if (a.nm == 1) return launch_lw_k<TM, TN, WM, WN, 1>(a, s);
-        return launch_lw_k<TM, TN, WM, WN, 3>(a, s);
-      }
-#endif
       if (a.fastk) {
         if (mf32 && a.nm == 3) return launch_dma_k<TM, TN, WM, WN, false, true>(a, s);
         if (a.nm == 2) return launch_dma_k<TM, TN, WM, WN, false, true, false, 2, true>(a, s);
@@ -1483,12 +1235,6 @@ __global__ __launch_bounds__(256) void softmax_rows_s16_reg_kernel(const float* 
     } else if (c < ld_out) {
       U8 hh, ll;
       split4(v[i] * inv, hh, ll, 0);
-#ifdef VFML_EXPERIMENT_ATT_HI_ONLY   // precision experiment: probabilities as one round-to-nearest f16
-      {
-        const f32x4 pv = v[i] * inv;
-        for (int e = 0; e < 4; ++e) { hh.v[e] = (_Float16)pv[e]; ll.v[e] = (_Float16)0.f; }
-      }
-#endif
       char* u = reinterpret_cast<char*>(orow + (c & ~7)) + (c & 4) * 2;
       *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hh.v, hh.v, 0, 1, 2, 3));
       *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(ll.v, ll.v, 0, 1, 2, 3));

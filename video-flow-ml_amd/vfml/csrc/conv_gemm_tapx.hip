@@ -22,22 +22,17 @@
 // (tests/test_gpu_kernels.py::test_tap_shared_stage_matches_the_per_tap_kernel).
 #include "conv_split_common.h"
 
-#ifdef VFML_TAPX_STAMPS    // experiment build (tools/exp/tapx_stamps.py): where a wave's cycles go, per phase of a step
-__device__ unsigned long long vfml_tapx_stamps[64];
-__device__ unsigned long long vfml_tapx_timeline[4096 * 4];
-extern "C" int vfml_debug_tapx_timeline(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(vfml_tapx_timeline), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : 1;
-}
-extern "C" int vfml_debug_tapx_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(vfml_tapx_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
-}
-#define STAMP(x)                                           \
-  do {                                                     \
-    x = __builtin_readcyclecounter();                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-  } while (0)
-#else
-#define STAMP(x)
+// In-kernel time stamps exist in an EXPERIMENT build only: tools/exp/tapx_stamps.py compiles this file with
+// `-include tools/exp/tapx_hooks.h`, which defines the hooks below (per-phase s_memtime sums of one workgroup, an
+// s_memrealtime timeline of every workgroup).  In the product they are empty.
+#ifndef VFML_TAPX_HOOKS
+#define TAPX_HOOK_ENTRY()
+#define TAPX_HOOK_KLOOP_BEGIN()
+#define TAPX_HOOK_STEP_BEGIN(st)
+#define TAPX_HOOK_STAMP(k)
+#define TAPX_HOOK_STEP_END()
+#define TAPX_HOOK_KLOOP_END(nsteps)
+#define TAPX_HOOK_EXIT()
 #endif
 
 namespace {
@@ -64,9 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sC = reinterpret_cast<float*>(smem_raw);
-#ifdef VFML_TAPX_STAMPS
-  const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
-#endif
+  TAPX_HOOK_ENTRY();
 
   // this workgroup's tile (XCD x = blockIdx & 7 owns a contiguous share of the tile space)
   const int total = a.mtiles * a.ntiles;
@@ -78,12 +71,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
     tile = start + lw;
     if (tile >= start + q + (xcd < r ? 1 : 0)) return;
   }
-#ifdef VFML_TAPX_PRIO   // experiment: the two workgroups of a CU at different priorities (dispatch order: 256 blocks per layer)
-  if (((blockIdx.x >> 8) & 1) == 0) __builtin_amdgcn_s_setprio(VFML_TAPX_PRIO);
-#endif
-#ifdef VFML_TAPX_DELAY  // experiment: the second workgroup of a CU starts VFML_TAPX_DELAY x 64 cycles late (out of phase)
-  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(VFML_TAPX_DELAY);
-#endif
   const int nt_ = tile % a.ntiles, mt_ = tile / a.ntiles;
   const int m0 = mt_ * TBM, n0 = nt_ * TBN;
 
@@ -181,11 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, sX = 0, sM = 0, sW = 0, sY = 0;
-#ifdef VFML_TAPX_STAMPS
-  const unsigned long long k0c = __builtin_readcyclecounter(), k0r = __builtin_amdgcn_s_memrealtime();
-#endif
-  (void)c0; (void)c1; (void)c2; (void)c3; (void)c4; (void)sX; (void)sM; (void)sW; (void)sY;
+  TAPX_HOOK_KLOOP_BEGIN();
   int st = 0;
   int cbn = 0, kyn = 0;                 // the stage being loaded (the one after the stage being computed)
   for (int sg = 0; sg < nstage; ++sg) {
@@ -198,10 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
     const bool next_stage = sg + 1 < nstage;
     for (int kx = 0; kx < a.kw; ++kx, ++st) {
       const bool next_step = st + 1 < nsteps;
-#ifdef VFML_TAPX_ALTPRIO  // experiment: the two workgroups of a CU take turns at the higher issue priority, VFML_TAPX_ALTPRIO steps each
-      if (((st / VFML_TAPX_ALTPRIO) ^ (blockIdx.x >> 8)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-      STAMP(c0);
+      TAPX_HOOK_STEP_BEGIN(st);
       // this step's weight fragments into registers, then the weight stage is free for the next step's pieces
       // (the fragments straight from the L2-resident weight planes into registers one step ahead - no weight stage, no
       // barrier X - measured 20-25 % slower: a fragment is 16 rows x 64 bytes, sixteen cache lines per load instruction)
@@ -223,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
         if constexpr (H64 || !AHI) a1 = *reinterpret_cast<const h16x8*>(smem_raw + (ad ^ X1));
       }
       __syncthreads();                                                                     // (X)
-      STAMP(c1);
+      TAPX_HOOK_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
       static_for<2 * TM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -260,26 +240,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
           if constexpr (H64 || !AHI) a1 = n1_;
         }
       });
-      STAMP(c2);
+      TAPX_HOOK_STAMP(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP(c3);
+      TAPX_HOOK_STAMP(3);
       __syncthreads();                                                                     // (Y)
-      STAMP(c4);
-#ifdef VFML_TAPX_STAMPS
-      sX += c1 - c0; sM += c2 - c1; sW += c3 - c2; sY += c4 - c3;
-#endif
+      TAPX_HOOK_STEP_END();
     }
   }
 
-#ifdef VFML_TAPX_STAMPS
-  const unsigned long long tl_kend = __builtin_amdgcn_s_memrealtime();
-  if (lane == 0 && blockIdx.x == gridDim.x / 2 + 3) {
-    vfml_tapx_stamps[wave * 8 + 0] = sX; vfml_tapx_stamps[wave * 8 + 1] = sM; vfml_tapx_stamps[wave * 8 + 2] = sW;
-    vfml_tapx_stamps[wave * 8 + 3] = sY; vfml_tapx_stamps[wave * 8 + 4] = (unsigned long long)nsteps;
-    vfml_tapx_stamps[wave * 8 + 5] = __builtin_readcyclecounter() - k0c;       // shader clocks of the K loop
-    vfml_tapx_stamps[wave * 8 + 6] = __builtin_amdgcn_s_memrealtime() - k0r;   // the same interval at the constant 100 MHz
-  }
-#endif
+  TAPX_HOOK_KLOOP_END(nsteps);
   // Epilogue in TM slabs through LDS: slab i holds block row i of every wave (WM*32 rows x TBN).
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -321,14 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_tapx_kernel(const SplitArgs 
       }
     }
   }
-#ifdef VFML_TAPX_STAMPS
-  if (t == 0 && blockIdx.x < 4096) {
-    vfml_tapx_timeline[blockIdx.x * 4 + 0] = tl_entry;
-    vfml_tapx_timeline[blockIdx.x * 4 + 1] = k0r;
-    vfml_tapx_timeline[blockIdx.x * 4 + 2] = tl_kend;
-    vfml_tapx_timeline[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  TAPX_HOOK_EXIT();
 }
 
 template <int TM, int TN, int WM, int WN, int NM>

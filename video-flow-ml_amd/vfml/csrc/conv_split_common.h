@@ -207,12 +207,8 @@ __device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* s
         U8 hi, lo;
         split4(v, hi, lo, 0);
         char* u = reinterpret_cast<char*>(a.out + (int64_t)grow * a.ldo + gcol) + 8 * q;
-#ifdef VFML_EXPERIMENT_NOEPISTORE     // timing only: the values are consumed, nothing is written
-        asm volatile("" ::"v"(hi.v), "v"(lo.v), "v"(u));
-#else
         *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
         *reinterpret_cast<uint2*>(u + 16) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
-#endif
       } else {
         float* o = a.out + (int64_t)grow * a.ldo + col;
         if (nvalid == 4 && a.vec_ok) {

@@ -506,7 +506,8 @@ class MOFNetHIP(_Holder):
         main = torch.cuda.current_stream(dev)
         side = self._side.get(dev)
         if side is None:
-            side = self._side[dev] = torch.cuda.Stream(device=dev)
+            # (VFML_PREFETCH_PRIO: HIP stream priority of the prefetch stream - larger = lower; A/B switch)
+            side = self._side[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("VFML_PREFETCH_PRIO", "0")))
         P = self._pack(dev)
         dbg = os.environ.get("VFML_PREFETCH_DBG", "")
         if "serial" in dbg:
