@@ -227,8 +227,10 @@ def main():
     # -- the other arithmetic plan on the next fields of the same job (N = 1 only): its own warm-up, then K timed fields
     alt = None
     if alt_precision:
-        first_plan = dict(core.cfg.mfma_plan or {})
+        first_plan, first_volume = dict(core.cfg.mfma_plan or {}), getattr(core.cfg, "corr_volume", "f32")
         core.cfg.precision, core.cfg.mfma_plan = alt_precision, None
+        if not args.corr_volume:
+            core.cfg.corr_volume = "f32"      # (the fp32-grade / plain-f16 comparison plans run on f32 volumes)
         core.model.clear_feature_cache()      # nothing of the first plan's cached frames / pyramids is of use to this one
         torch.cuda.synchronize()
         base = Wm + K + En
@@ -241,6 +243,7 @@ def main():
         assert np.isfinite(out[-1]).all()
         del out
         core.cfg.precision = precision
+        core.cfg.corr_volume = first_volume
         if precision == "mixed":
             core.cfg.mfma_plan = dict(first_plan)
         core.model.clear_feature_cache()

@@ -543,7 +543,8 @@ MIXED_TOL = 1e-4    # px: the mixed plan's budget at 1080p, a tenth of north_sta
 
 
 def test_mixed_plan_stays_within_its_budget_at_1080p(gpu):
-    """cfg.precision='mixed' with the shipped plan (vfml/cfg.py DEFAULT_MIXED_PLAN): mean EPE <= 1e-4 px at
+    """cfg.precision='mixed' with the shipped plan (vfml/cfg.py DEFAULT_MIXED_PLAN + DEFAULT_MIXED_CORR_VOLUME: the coarsest
+    pyramid level as f16 - what VideoFlowCore runs by default): mean EPE <= 1e-4 px at
     1920x1080 on three weight seeds and for T in {3, 5}.  Reference: the CPU oracle for seed 0 (both T); for seeds 1
     and 2 the engine's own exact-f32 arithmetic (cfg.precision='f32', v_mfma_f32_32x32x2_f32 - itself within 3e-6 px
     of the oracle: test_model_forward_matches_oracle and bench.py's cpu_baseline) - a full-size oracle field costs
@@ -551,7 +552,7 @@ def test_mixed_plan_stays_within_its_budget_at_1080p(gpu):
     import numpy as np
     from oracle import mof_oracle as mo
     from vfml import build_network, get_cfg
-    from vfml.cfg import DEFAULT_MIXED_PLAN
+    from vfml.cfg import DEFAULT_MIXED_CORR_VOLUME, DEFAULT_MIXED_PLAN
     from vfml.synth import synthetic_clip
     from vfml.weights import seeded_state_dict
     H, W = 1080, 1920
@@ -567,6 +568,7 @@ def test_mixed_plan_stays_within_its_budget_at_1080p(gpu):
             c.precision = prec
             if prec == "mixed":
                 c.mfma_plan = dict(DEFAULT_MIXED_PLAN)
+                c.corr_volume = DEFAULT_MIXED_CORR_VOLUME
             n = build_network(c)
             n.load_state_dict(sd)
             nets[prec] = n.cuda().eval()

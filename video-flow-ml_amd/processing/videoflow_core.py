@@ -58,8 +58,11 @@ class VideoFlowCore:
             if self.precision == "mixed":
                 from vfml.cfg import DEFAULT_MIXED_PLAN
                 cfg.mfma_plan = dict(self.mfma_plan if self.mfma_plan is not None else DEFAULT_MIXED_PLAN)
-        if os.environ.get("VFML_CORR_VOLUME"):     # 'f16': half-size correlation pyramids (vfml/cfg.py corr_volume)
+        if os.environ.get("VFML_CORR_VOLUME"):     # 'f16' / 'f16@k': correlation pyramids (from level k up) as f16 (vfml/cfg.py)
             cfg.corr_volume = os.environ["VFML_CORR_VOLUME"]
+        elif self.precision == "mixed" and self.mfma_plan is None:
+            from vfml.cfg import DEFAULT_MIXED_CORR_VOLUME      # (part of the shipped plan's measured EPE budget)
+            cfg.corr_volume = DEFAULT_MIXED_CORR_VOLUME
         if not os.path.exists(model_path):
             raise FileNotFoundError(f"VideoFlow model weights not found: {model_path}")
         self.cfg = cfg

@@ -60,6 +60,10 @@ BOF_F16_PLAN = {
     f"{_UB}.gru.convq2.iter": "2a",
     f"{_UB}.flow_head.conv1": "2a", f"{_UB}.flow_head.conv2": "2a",
 }
+# Pyramid storage that goes with the shipped mixed plan: the coarsest level as f16 (profiles/r03_corr_volume_levels.md: worst mean
+# EPE over three seeds x T in {3, 5} at 1080p 8.8e-5 px against 7.7e-5 with f32 volumes, budget 1e-4; +0.6 % fields/s).  Levels
+# 2-3 (1.00e-4) and beyond do not fit the budget.
+DEFAULT_MIXED_CORR_VOLUME = "f16@3"
 NAMED_PLANS = {"default": DEFAULT_MIXED_PLAN, "bof-f16": BOF_F16_PLAN}     # VFML_MFMA_PLAN may name one
 
 # (A/B switch: VFML_PLAN_EXCLUDE="layer,layer" takes entries out of the default plan - those layers run all three terms)
