@@ -274,7 +274,7 @@ class _Unpacker(threading.Thread):
 
 
 def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, group=None, on_field=None,
-                collect=True, num_lods=0, chunk=None, feeder=None, prepare_only=False, local_sink=None):
+                collect=True, num_lods=0, chunk=None, feeder=None, prepare_only=False, local_sink=None, out=None):
     """Compute the flow field of every frame in `frame_indices` of the device-resident uint8 clip [F,H,W,3]
     (`clip` may be None when a ClipFeeder is given: its clip is used and fed as the job advances).
     Returns on rank 0 a float32 numpy array [len(frame_indices), H, W, 2] (None with collect=False, when the
@@ -286,7 +286,10 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     to the reference's loop).
     `local_sink(k, field, lods)` (whole-frame jobs only; excludes collect / on_field): called on EVERY rank for that
     rank's own fields - no collective, nothing funnels into rank 0 (the CLI's per-rank cache writers).
-    prepare_only: allocate the job's staging buffers (kept for later jobs of the same geometry) and return."""
+    prepare_only: allocate the job's staging buffers (kept for later jobs of the same geometry) and return.
+    out: optional result array (rank 0, with collect): float32 [len(frame_indices), H, W, 2], filled and returned instead of a
+    fresh one - a caller that times the job hands in memory it has already touched (at 8 ranks x 41 fields/s the result
+    grows by 5 GB/s; first-touch page faults of a fresh array would be part of what is measured)."""
     frame_indices = list(frame_indices)
     if feeder is not None:
         clip = feeder.clip
@@ -337,7 +340,13 @@ def run_sharded(proc, clip, frame_indices, tile_mode=False, rank=0, world=1, gro
     side = torch.cuda.Stream(device=dev) if on_gpu and sink_here else None
     seq = getattr(proc, "sequence_length", 1)
 
-    out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32) if (rank == 0 and collect and not local) else None
+    if rank == 0 and collect and not local:
+        if out is None:
+            out = np.zeros((len(frame_indices), H, W, 2), dtype=np.float32)
+        elif out.shape != (len(frame_indices), H, W, 2) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {(len(frame_indices), H, W, 2)}")
+    else:
+        out = None
     slot_of = {f: k for k, f in enumerate(frame_indices)}
     partial, left = {}, {}                                  # tile mode without `collect`: frames being assembled
     tile_lock = threading.Lock()
