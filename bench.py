@@ -384,11 +384,15 @@ def whole_jobs(precision):
     import subprocess
     env = dict(os.environ, VFML_PRECISION=precision or "mixed")
     out = {}
+    t_start = time.perf_counter()
+    BUDGET_S, CHILD_S = 300.0, 180.0      # (a child takes ~25 s; the line must come out even if one of them hangs)
 
     def run(*argv):
+        if time.perf_counter() - t_start > BUDGET_S:
+            return {"error": "skipped: the whole-job figures' time budget was spent"}
         try:
             p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "job_bench.py"), *argv], env=env,
-                               capture_output=True, text=True, timeout=420)
+                               capture_output=True, text=True, timeout=CHILD_S)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode == 0 and line:
                 return json.loads(line[-1])
