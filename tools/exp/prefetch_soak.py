@@ -8,12 +8,12 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(ROOT, "video-flow-ml_amd")); sys.path.insert(0, ROOT)
 import torch
 from vfml import build_network, get_cfg
-from vfml.cfg import DEFAULT_MIXED_PLAN
+from vfml.cfg import DEFAULT_MIXED_CORR_VOLUME, DEFAULT_MIXED_PLAN
 from vfml.synth import synthetic_clip
 from vfml.weights import seeded_state_dict
 from processing.videoflow_processor import VideoFlowProcessor
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-cfg = get_cfg(); cfg.precision = "mixed"; cfg.mfma_plan = dict(DEFAULT_MIXED_PLAN)
+cfg = get_cfg(); cfg.precision = "mixed"; cfg.mfma_plan = dict(DEFAULT_MIXED_PLAN); cfg.corr_volume = DEFAULT_MIXED_CORR_VOLUME      # (what VideoFlowCore runs by default)
 net = build_network(cfg); net.load_state_dict(seeded_state_dict(cfg, 0)); net = net.cuda().eval()
 with contextlib.redirect_stdout(io.StringIO()):
     proc = VideoFlowProcessor("cuda", sequence_length=5)
