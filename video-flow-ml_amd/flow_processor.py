@@ -5,7 +5,8 @@ Same flags as the reference CLI (flow_processor.py:1272-1332) and the same flow-
 (cache directory name, flow_frame_%06d.npz members, completeness check, optional LODs), with the
 frame loop of its cache-filling paths (:959-976 normal mode, :1460-1470 --interactive) running on
 the MI355X engine and, under `python -m torch.distributed.run --nproc-per-node N flow_processor.py …`,
-sharded over N GPUs with one RCCL gather (vfml.runner).
+sharded over N GPUs (vfml.runner): whole-frame jobs with no collective at all - every rank writes the
+cache files of its own fields - tiled jobs with the tiles streaming to rank 0 in chunked RCCL gathers.
 
 Out of scope here: decoding/encoding video with OpenCV, flow visualisation encoders,
 TAA, the side-by-side composer and the Tk/Qt tools; flags that only concern those are accepted and
