@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 23
+#define VFML_ABI_VERSION 24
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -298,6 +298,19 @@ int vfml_convex_upsample(const float* coords1, int ch, const float* mask, int ld
 int64_t vfml_instnorm_finalize_workspace_bytes(int chunks, int c);   /* 0: this shape folds without a workspace */
 int vfml_instnorm_finalize(const double* part, int n, int chunks, int c, int hw, float eps, float* stats,
                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The encoders' stem (K2's first layer): 7x7 convolution, stride 2, padding 3, 4 -> 64 channels, over NHWC4 frames
+ * (vfml_frames_to_nhwc4's output) in the split-f16 arithmetic (three MFMAs per product), as one kernel that keeps a tile's
+ * input patch and all weights in LDS (csrc/stem.hip).
+ *   frames      [n][h][w][4] f32;  out [n][ho][wo][64] f32, ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1
+ *   w_hi, w_lo  f16 planes [64][224] of the weights times w_scale, K order ky-major: k = ky * 32 + kx * 4 + c with kx < 8
+ *               (kx = 7: zeros) and c < 4 - what vfml_split_f16 makes of a [64][7][8][4] f32 tensor
+ *   stats_part  NULL, or [n][vfml_stem7x7s2_chunks(h, w)][64][2] doubles: {sum, sum of squares} of the stored values per
+ *               8 x 64-pixel output tile and channel - fold with vfml_instnorm_finalize(chunks = that count)
+ * Replaces: the first nn.Conv2d(3, 64, 7, stride=2, padding=3) of the RAFT encoder. */
+int vfml_stem7x7s2_chunks(int h, int w);
+int vfml_stem7x7s2(const float* frames, int n, int h, int w, const void* w_hi, const void* w_lo, float w_scale,
+                   const float* bias, float* out, double* stats_part, void* stream);
 
 /* One level of the flow-cache LOD pyramid (reference storage/cache_manager.py:77-161): out[y][x] =
  * 0.5 * (sum of the 2x2 block's in-image vectors) / (number of in-image cells); odd sides are padded

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), f"{n} declared in include/vfml.h but not exported"
     assert sorted(hip.EXPORTS) == names
     lib.vfml_abi_version.restype = ctypes.c_int
-    assert lib.vfml_abi_version() == 23
+    assert lib.vfml_abi_version() == 24
 
 
 def test_argument_validation_needs_no_gpu():

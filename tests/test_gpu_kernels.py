@@ -1160,3 +1160,65 @@ def test_flow_rows7_turns_the_7x7_flow_convolution_into_7x1(gpu):
     assert torch.isfinite(got).all()
     assert rel_err(got, ref) < CONV_TOL["f16x3"], rel_err(got, ref)
     del back
+
+
+@pytest.mark.parametrize("n,H,W", [(1, 64, 128), (2, 70, 90), (1, 136, 200), (1, 1080, 1920)])
+def test_stem_kernel_matches_the_general_convolution(gpu, n, H, W):
+    """vfml_stem7x7s2 (csrc/stem.hip: the encoders' 7x7 / 2 stem with the tile's input patch and all weights resident in
+    LDS): against a float64 convolution, against the general split-f16 kernel it replaces (same three-term products, other
+    grouping of the K axis: equal to f32 rounding), and its per-tile statistics partials - folded by vfml_instnorm_finalize
+    - against vfml_instnorm_stats over the stored map.  Exact tile multiples, ragged edges in both directions (odd output
+    sizes), two images, and the 1080p frame."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.rand(n, 3, H, W, generator=g) * 2 - 1
+    wt = torch.randn(64, 3, 7, 7, generator=g) / (3 * 49) ** 0.5
+    b = torch.randn(64, generator=g)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    hw = ho * wo
+    x4 = torch.cat([x, torch.zeros(n, 1, H, W)], dim=1)
+    xd = nhwc(x4)
+    sw = hip.pack_stem_weight(wt.cuda(), torch.device("cuda"))
+    out = torch.full((n * hw * 64 + 64,), float("nan"), device=gpu)
+    chunks = hip.stem_chunks(H, W)
+    part = torch.full((n * chunks * 64 * 2 + 8,), float("nan"), device=gpu, dtype=torch.float64)
+    hip.stem7x7s2(xd, n, H, W, sw, b.to(gpu), out, stats_part=part)
+    torch.cuda.synchronize()
+    assert torch.isnan(out[n * hw * 64:]).all() and not torch.isnan(out[:n * hw * 64]).any()
+    assert torch.isnan(part[n * chunks * 64 * 2:]).all() and not torch.isnan(part[:n * chunks * 64 * 2]).any()
+    got = from_nhwc(out[:n * hw * 64], n, ho, wo, 64)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=3)
+    assert rel_err(got.double(), ref) < CONV_TOL["f16x3"], rel_err(got.double(), ref)
+    # the general kernel on the same operands (tap-major weights over the padded 4 channels)
+    wobj = as_weight(pack_conv_weight(wt, cin_pad=4), 64, "f16x3")
+    old = torch.empty(n * hw * 64, device=gpu)
+    hip.conv2d(xd, 4, 4, n, H, W, wobj, b.to(gpu), 64, 7, 7, old, 64, stride=2, pad_h=3, pad_w=3)
+    assert rel_err(out[:n * hw * 64].cpu(), old.cpu()) < 2e-6
+    # statistics: partials folded == the stand-alone pass over the stored map; means against float64
+    st_a = torch.empty(n * 64 * 2, device=gpu)
+    st_b = torch.empty_like(st_a)
+    hip.instnorm_finalize(part, n, chunks, 64, hw, st_a)
+    ws = torch.empty(hip.instnorm_workspace_bytes(n, hw, 64) // 8 + 1, device=gpu, dtype=torch.float64)
+    hip.instnorm_stats(out[:n * hw * 64].clone(), n, hw, 64, st_b, ws)
+    assert torch.allclose(st_a, st_b, rtol=2e-7, atol=1e-9), (st_a - st_b).abs().max().item()
+    assert torch.allclose(st_a.view(n, 64, 2)[..., 0].cpu().double(), got.double().mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+    # without the partials: same map
+    out2 = torch.empty(n * hw * 64, device=gpu)
+    hip.stem7x7s2(xd, n, H, W, sw, None, out2)
+    assert torch.allclose(out2.view(-1, 64) + b.to(gpu), out[:n * hw * 64].view(-1, 64), rtol=0, atol=1e-5)
+    if (H, W) == (1080, 1920):
+        for fn, name in ((lambda: hip.stem7x7s2(xd, n, H, W, sw, b.to(gpu), out, stats_part=part), "stem kernel"),
+                         (lambda: hip.conv2d(xd, 4, 4, n, H, W, wobj, b.to(gpu), 64, 7, 7, old, 64, stride=2, pad_h=3, pad_w=3,
+                                             stats_part=torch.empty(n * ((hw + 127) // 128) * 64 * 2, device=gpu, dtype=torch.float64)),
+                          "general kernel")):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            print(f"stem 1080p: {name} {us:.1f} us per launch = {2.0 * hw * 196 * 64 / us / 1e6:.1f} TFLOP/s algorithmic")

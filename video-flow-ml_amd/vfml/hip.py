@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFML_LIB") or os.path.join(_HERE, "libvfml_hip.so")   # VFML_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "stem.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
 
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
@@ -131,6 +131,8 @@ def lib():
     L.vfml_instnorm_finalize.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int64, c_void_p]
     L.vfml_instnorm_finalize_workspace_bytes.restype = c_int64
     L.vfml_instnorm_finalize_workspace_bytes.argtypes = [c_int, c_int]
+    L.vfml_stem7x7s2_chunks.argtypes = [c_int, c_int]
+    L.vfml_stem7x7s2.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
     L.vfml_instnorm_apply.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]
     L.vfml_avgpool2x2.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_corr_lookup.argtypes = [POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
@@ -153,7 +155,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 23:
+    if L.vfml_abi_version() != 24:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -164,7 +166,7 @@ EXPORTS = [
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
     "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_flow_rows7",
-    "vfml_convex_upsample", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
+    "vfml_convex_upsample", "vfml_stem7x7s2", "vfml_stem7x7s2_chunks", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
 
@@ -435,6 +437,32 @@ def instnorm_finalize(part, n, chunks, c, hw, stats, eps=1e-5, workspace=None):
                                         c_void_p(workspace.data_ptr()) if workspace is not None else None,
                                         workspace.numel() * 8 if workspace is not None else 0, _stream()),
            "vfml_instnorm_finalize")
+
+
+def stem_chunks(h, w):
+    return int(lib().vfml_stem7x7s2_chunks(h, w))
+
+
+def pack_stem_weight(w, device):
+    """[64, 3|4, 7, 7] conv weight -> SplitWeight planes [64][224] in the stem kernel's K order (ky-major rows of 8 taps x 4
+    channels, tap 7 and channel 3 zero)."""
+    w = w.detach().to(device=device, dtype=torch.float32)
+    cout, cin = w.shape[0], w.shape[1]
+    if cout != 64 or cin not in (3, 4) or tuple(w.shape[2:]) != (7, 7):
+        raise ValueError(f"pack_stem_weight: a [64, 3|4, 7, 7] weight expected, got {tuple(w.shape)}")
+    k = torch.zeros(cout, 7, 8, 4, device=device)
+    k[:, :, :7, :cin] = w.permute(0, 2, 3, 1)
+    sw = SplitWeight(cout, 224, device)
+    return sw.fill(k.reshape(-1).contiguous(), scale=SplitWeight.auto_scale(float(w.abs().max())))
+
+
+def stem7x7s2(frames, n, h, w, weight, bias, out, stats_part=None):
+    """vfml_stem7x7s2: frames f32 [n,h,w,4] -> out f32 [n,ho,wo,64] (+ per-tile statistics partials)."""
+    if not isinstance(weight, SplitWeight) or weight.rows != 64 or weight.kp != 224:
+        raise ValueError("stem7x7s2: weight must come from pack_stem_weight")
+    _check(lib().vfml_stem7x7s2(_ptr(_dev(frames)), n, h, w, c_void_p(weight.hi.data_ptr()), c_void_p(weight.lo.data_ptr()),
+                                weight.scale, _ptr(_dev(bias)) if bias is not None else None, _ptr(_dev(out)),
+                                c_void_p(stats_part.data_ptr()) if stats_part is not None else None, _stream()), "vfml_stem7x7s2")
 
 
 def instnorm_apply(x, stats, n, hw, c, out, res=None, res_stats=None, out_fmt=FMT_F32):

@@ -194,6 +194,13 @@ class MOFNetHIP(_Holder):
                     sw.order = (hip.KORDER_CBLOCK64 if name in cb64_names else
                                 hip.KORDER_CBLOCK if name in cblock_names else hip.KORDER_TAP)
                     P[name] = (sw, b)
+        if split and os.environ.get("VFML_STEM", "1") != "0":        # (A/B switch: the general kernel for the stems)
+            for enc in ("fnet", "cnet"):
+                leaf = self._param(f"{enc}.conv1")
+                if tuple(leaf.weight.shape) == (64, 3, 7, 7):
+                    with torch.cuda.device(device):
+                        P[f"{enc}.conv1.stem"] = (hip.pack_stem_weight(leaf.weight, device),
+                                                  leaf.bias.detach().to(device=device, dtype=torch.float32).contiguous())
         self._tapsum = bool(cout_packed)
         self._rows7 = bool(rows7)
         self._packed, self._packed_key = P, key
@@ -390,7 +397,17 @@ class MOFNetHIP(_Holder):
             hip.instnorm_finalize(part, n, chunks, planes, hw, s, workspace=fold_ws)
             return s
 
-        s0 = conv_stats(x, 4, H, W, f"{prefix}.conv1", 64, raw, 0, 7, stride=2, pad=3)
+        stem = P.get(f"{prefix}.conv1.stem")
+        if stem is not None and split_prec and self._nm(f"{prefix}.conv1") == 3:
+            # the 7x7 / 2 stem as one patch-resident kernel (csrc/stem.hip): its statistics partials are one chunk per
+            # 8 x 64-pixel output tile
+            chunks = hip.stem_chunks(H, W)
+            part = parts[0:]
+            hip.stem7x7s2(x, n, H, W, stem[0], stem[1], raw, stats_part=part)
+            s0 = st[0:]
+            hip.instnorm_finalize(part, n, chunks, 64, h2 * w2, s0, workspace=fold_ws)
+        else:
+            s0 = conv_stats(x, 4, H, W, f"{prefix}.conv1", 64, raw, 0, 7, stride=2, pad=3)
         cur = act[0]
         hip.instnorm_apply(raw, s0, n, h2 * w2, 64, cur, out_fmt=AF)
         ch, hh, ww, ci = 64, h2, w2, 0
