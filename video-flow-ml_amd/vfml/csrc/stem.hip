@@ -53,22 +53,50 @@ __global__ __launch_bounds__(512, 2) void stem7x7s2_kernel(const StemArgs a) {
   const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;        // input pixel under patch (0, 0)
 
   // ---- stage the patch (f32 -> hi / lo halves) and the weights -------------------------------------------------
+  // (all of a thread's loads are requested before the first one is used: unconditional loads on clamped addresses, the value
+  // zeroed afterwards where the patch leaves the image - a load behind a branch makes hipcc wait for each one in turn)
   const f32x4* src = a.frames + (int64_t)img * a.H * a.W;
-  for (int p = t; p < ST_PH * ST_PW; p += 512) {
+  constexpr int NPP = (ST_PH * ST_PW + 511) / 512;        // patch pixels per thread (6)
+  constexpr int NWC = 64 * (ST_K / 8);                    // 16-byte weight chunks per plane: 28 per row
+  constexpr int NWP = (NWC + 511) / 512;                  // ... per thread (4)
+  f32x4 pv[NPP];
+  bool pok[NPP];
+  u32x4 wh[NWP], wl[NWP];
+  static_for<NPP>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int p = min(t + 512 * q, ST_PH * ST_PW - 1);
     const int py = p / ST_PW, px = p - py * ST_PW;
     const int iy = iy0 + py, ix = ix0 + px;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = src[(int64_t)iy * a.W + ix];
-    U8 hi, lo;
-    split4(v, hi, lo, 0);
-    *reinterpret_cast<uint2*>(p_hi + p * 8) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
-    *reinterpret_cast<uint2*>(p_lo + p * 8) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
-  }
-  for (int c = t; c < 64 * (ST_K / 8); c += 512) {        // 16-byte chunks: 28 per weight row
+    pok[q] = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    pv[q] = src[(int64_t)min(max(iy, 0), a.H - 1) * a.W + min(max(ix, 0), a.W - 1)];
+  });
+  static_for<NWP>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int c = min(t + 512 * q, NWC - 1);
     const int row = c / (ST_K / 8), col = c - row * (ST_K / 8);
-    *reinterpret_cast<uint4*>(w_hi + row * (ST_WP * 2) + col * 16) = *reinterpret_cast<const uint4*>(a.whi + row * ST_K + col * 8);
-    *reinterpret_cast<uint4*>(w_lo + row * (ST_WP * 2) + col * 16) = *reinterpret_cast<const uint4*>(a.wlo + row * ST_K + col * 8);
-  }
+    wh[q] = *reinterpret_cast<const u32x4*>(a.whi + row * ST_K + col * 8);
+    wl[q] = *reinterpret_cast<const u32x4*>(a.wlo + row * ST_K + col * 8);
+  });
+  static_for<NPP>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int p = t + 512 * q;
+    if (p < ST_PH * ST_PW) {
+      const f32x4 v = pok[q] ? pv[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      U8 hi, lo;
+      split4(v, hi, lo, 0);
+      *reinterpret_cast<uint2*>(p_hi + p * 8) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+      *reinterpret_cast<uint2*>(p_lo + p * 8) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+    }
+  });
+  static_for<NWP>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const int c = t + 512 * q;
+    if (c < NWC) {
+      const int row = c / (ST_K / 8), col = c - row * (ST_K / 8);
+      *reinterpret_cast<u32x4*>(w_hi + row * (ST_WP * 2) + col * 16) = wh[q];
+      *reinterpret_cast<u32x4*>(w_lo + row * (ST_WP * 2) + col * 16) = wl[q];
+    }
+  });
   __syncthreads();
 
   // ---- K loop: one filter row per step, everything resident -----------------------------------------------------
