@@ -358,6 +358,12 @@ def main():
                     f"events on the launch stream, the next window's encoders queued behind the field instead of beside it "
                     f"({1000.0 * t_prof / Pn:.2f} ms per field that way)",
             "share_of_pass": d["ms"] / (1000.0 * t_prof),
+            # the layers behind that kernel symbol, by shape "khxkw cin->cout" (the 1x1 motion-encoder layer streams its 672
+            # input channels once and is the memory-side outlier of the four: tools/exp/r03_l2_touch/README.md)
+            "by_shape": {k: {"launches": v["launches"], "avg_launch_us": 1000.0 * v["ms"] / v["launches"],
+                             "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                             "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak}
+                         for k, v in sorted(d.get("shapes", {}).items(), key=lambda kv: -kv[1]["ms"])},
             "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                  "launches": v["launches"]} for k, v in prof.items()},
             # the HBM-bound stages of the path beside it: algorithmic bytes / HIP-event time

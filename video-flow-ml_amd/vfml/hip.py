@@ -224,19 +224,22 @@ def profile_end_hbm():
 
 
 def profile_end():
-    """Stop recording; returns {variant: {"launches", "flops", "bytes", "ms"}} (synchronises); bytes = every operand
-    read once and the result written once (the algorithmic HBM traffic of the launch)."""
+    """Stop recording; returns {variant: {"launches", "flops", "bytes", "ms", "shapes"}} (synchronises); bytes = every operand
+    read once and the result written once (the algorithmic HBM traffic of the launch); shapes = the same sums per layer
+    shape "khxkw cin->cout" (one kernel variant serves several layers: bench.py's roofline.by_shape)."""
     global _PROFILE, _PROFILE_HBM
     rec, _PROFILE = _PROFILE or [], None
     _PROFILE_HBM = None
     torch.cuda.synchronize()
     out = {}
-    for variant, flops, nbytes, e0, e1 in rec:
-        d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
-        d["launches"] += 1
-        d["flops"] += flops
-        d["bytes"] += nbytes
-        d["ms"] += e0.elapsed_time(e1)
+    for variant, flops, nbytes, e0, e1, shape in rec:
+        d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "shapes": {}})
+        ms = e0.elapsed_time(e1)
+        for t in (d, d["shapes"].setdefault(shape, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})):
+            t["launches"] += 1
+            t["flops"] += flops
+            t["bytes"] += nbytes
+            t["ms"] += ms
     return out
 
 
@@ -396,7 +399,8 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
                      2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)
-                            + cout * kh * kw * (c0 + c1) * (0.5 if is_split and weight.lo is None else 1.0)), e0, e1))
+                            + cout * kh * kw * (c0 + c1) * (0.5 if is_split and weight.lo is None else 1.0)), e0, e1,
+                     f"{kh}x{kw} {c0 + c1}->{cout}"))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):
