@@ -365,7 +365,10 @@ def main():
                              "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak}
                          for k, v in sorted(d.get("shapes", {}).items(), key=lambda kv: -kv[1]["ms"])},
             "all_variants": {k: {"ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                                 "launches": v["launches"]} for k, v in prof.items()},
+                                 "launches": v["launches"],
+                                 "shapes": {sk: [sv["launches"], round(1000.0 * sv["ms"] / sv["launches"], 1),
+                                                 round(sv["flops"] / (sv["ms"] * 1e-3) / 1e12, 1)]     # launches, us, TFLOP/s
+                                            for sk, sv in v.get("shapes", {}).items()}} for k, v in prof.items()},
             # the HBM-bound stages of the path beside it: algorithmic bytes / HIP-event time
             "hbm_kernels": {k: {"bound": "hbm", "achieved": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,

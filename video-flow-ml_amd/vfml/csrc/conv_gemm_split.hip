@@ -900,8 +900,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       // accumulators - a lane holds four consecutive channels of a pixel - with 8-byte loads and stores, no LDS: measured
       // 0.7 ms per 1080p field slower than the rows below.)
       {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      static_for<TM>([&](auto slab) {       // (static_for, not `#pragma unroll`: the body is large and a slab loop left rolled
+        constexpr int i = decltype(slab)::value;   // would index the accumulators dynamically - scratch)
         __syncthreads();     // every wave is done with the stage buffers / with the previous slab
         if constexpr (MF16) {
           // 16 x 16 tiles: a lane's quad = pixel row lane & 15, output channels 4 (lane >> 4) .. + 3; block row i = tile
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
             }
           }
         }
-      }
+      });
       }
     }
     if (!PERSIST || next >= tile_end) break;

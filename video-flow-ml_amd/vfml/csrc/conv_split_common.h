@@ -267,8 +267,8 @@ __device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const f
     if (whole) bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + gcol + 4);
   }
   const bool lowhalf = gcol < a.split;          // split is a multiple of 8 here: a unit never straddles it
-  // The addend / aux units of a row are requested one row ahead, BEFORE the previous row's stores: vmcnt counts in order,
-  // a load issued behind a store could only be waited for together with the store's acknowledgement.
+  // The addend / aux units of a row are requested BEFORE any store of its batch: vmcnt counts in order, a load issued behind
+  // a store could only be waited for together with the store's acknowledgement.
   struct RowOps {
     f32x4 add[2], x0[2], x1[2];
   };
@@ -289,39 +289,48 @@ __device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const f
       load_unit16(a.aux1, (int64_t)grow * a.ld_aux1 + gcol, o.x1);
     }
   };
-  RowOps cur, nxt;
-  load_row(t / C8, cur);
-  for (int row = t / C8; row < nrows; row += RPP) {
-    const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
-    load_row(row + RPP, nxt);
-    if (grow < a.M) {
-      f32x4 v[2];
-      v[0] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8]);
-      v[1] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4]);
+  // EB rows per thread in flight: the addend / aux loads of a batch all go out before its first row is touched.  (Round 3:
+  // with ONE row requested ahead, every row of a GRU epilogue waited out a whole memory round trip - the work between a
+  // load and its use was ~200 cycles - and the four gate convolutions of an iteration ran 24-40 us longer than the same
+  // shapes with a plain ReLU epilogue: tools/exp/r03_l2_touch/README.md.  A 64-row slab is one batch per thread.)
+  // (the q gate's rows carry three operands, 24 registers each, beside the accumulators of the slabs still to come: two)
+  constexpr int EB = EPI == VFML_EPI_GRU_Q ? 2 : 4;
+  for (int row0 = t / C8; row0 < nrows; row0 += EB * RPP) {
+    RowOps ops[EB];
+    static_for<EB>([&](auto bc) { load_row(row0 + decltype(bc)::value * RPP, ops[decltype(bc)::value]); });
+    static_for<EB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      const int row = row0 + b * RPP;
+      const int grow = m0 + (row >> 5) * rstride + roff + (row & 31);
+      if (row < nrows && grow < a.M) {
+        const RowOps& cur = ops[b];
+        f32x4 v[2];
+        v[0] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8]);
+        v[1] = *reinterpret_cast<const f32x4*>(&sC[row * LDC + c8 * 8 + 4]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[q][e] = (v[q][e] * a.w_inv + cur.add[q][e] + bias4[q][e]) * a.out_scale;
-      epi_unit<EPI>(v, cur.x0, cur.x1, lowhalf);
-      if (a.out16) {
-        U8 hi, lo;
-        split4(v[0], hi, lo, 0);
-        split4(v[1], hi, lo, 4);
-        float* u = a.out + (int64_t)grow * a.ldo + gcol;
-        if (whole) {
-          *reinterpret_cast<h16x8*>(u) = hi.v;
-          *reinterpret_cast<h16x8*>(u + 4) = lo.v;
-        } else {       // the unit's second quad belongs to someone else (the motion features' flow channels)
-          *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
-          *reinterpret_cast<uint2*>(u + 4) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+          for (int e = 0; e < 4; ++e) v[q][e] = (v[q][e] * a.w_inv + cur.add[q][e] + bias4[q][e]) * a.out_scale;
+        epi_unit<EPI>(v, cur.x0, cur.x1, lowhalf);
+        if (a.out16) {
+          U8 hi, lo;
+          split4(v[0], hi, lo, 0);
+          split4(v[1], hi, lo, 4);
+          float* u = a.out + (int64_t)grow * a.ldo + gcol;
+          if (whole) {
+            *reinterpret_cast<h16x8*>(u) = hi.v;
+            *reinterpret_cast<h16x8*>(u + 4) = lo.v;
+          } else {       // the unit's second quad belongs to someone else (the motion features' flow channels)
+            *reinterpret_cast<uint2*>(u) = __builtin_bit_cast(uint2, __builtin_shufflevector(hi.v, hi.v, 0, 1, 2, 3));
+            *reinterpret_cast<uint2*>(u + 4) = __builtin_bit_cast(uint2, __builtin_shufflevector(lo.v, lo.v, 0, 1, 2, 3));
+          }
+        } else {
+          float* o = a.out + (int64_t)grow * a.ldo + gcol;
+          *reinterpret_cast<f32x4*>(o) = v[0];
+          if (whole) *reinterpret_cast<f32x4*>(o + 4) = v[1];
         }
-      } else {
-        float* o = a.out + (int64_t)grow * a.ldo + gcol;
-        *reinterpret_cast<f32x4*>(o) = v[0];
-        if (whole) *reinterpret_cast<f32x4*>(o + 4) = v[1];
       }
-    }
-    cur = nxt;
+    });
   }
 }
 
