@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VFML_ABI_VERSION 24
+#define VFML_ABI_VERSION 25
 
 /* Epilogue selector of vfml_conv2d.  v = out_scale * (acc + addend[p][c] + bias[c]). */
 enum {
@@ -98,6 +98,17 @@ typedef struct vfml_conv_desc {
                                                        items per tile, one per half of K: the second half's sums go to
                                                        the workspace and are added to out / out_t (first + second, a
                                                        fixed order) by passes the call launches itself */
+  /* optional projection epilogue (vfml_conv2d_split; split-row sources, VFML_EPI_RELU, no addend, cout % 128 == 0, the
+     full split product): relu(out) is NOT stored (out is not written).  Per 128-column tile t of the output the kernel
+     multiplies the tile, still in LDS, by that tile's slice of a second weight [proj_n][cout] and stores the partial sums
+         proj_out[t][p][j] = sum_{c in 128 t .. 128 t + 127} relu(out[p][c]) * proj_w[j][c],   j < proj_n <= 48,
+     proj_out = [cout / 128][n*ho*wo][ld_proj] floats; the caller adds the cout / 128 maps (vfml_tapsum3x3 does).  proj_hi /
+     proj_lo: the f16 planes [proj_n][proj_kp] of proj_w * proj_scale (vfml_split_f16; lo behind hi within 1 GiB), three
+     MFMAs per product.  The flow head - 3x3 to 256 channels, ReLU, 256 -> 4 over 3x3 as a 1x1 to 36 tap-major columns -
+     as ONE launch whose 256-channel map never travels to HBM and back.  Replaces: the second cuDNN conv of
+     FlowHead. */
+  const void* proj_hi; const void* proj_lo; int32_t proj_n; int32_t proj_kp; float proj_scale;
+  float* proj_out; int32_t ld_proj;
 } vfml_conv_desc;
 
 /* flags: accumulate the two cross terms of the split product in the order (a_lo*b_hi, a_hi*b_lo) instead of
@@ -266,8 +277,11 @@ int vfml_flow_rows7(const float* flow, int n, int h, int w, float* rows, void* s
  * sum_c w[o][c][ky][kx] x[.][c]) followed by this pass: out[p][o] = bias[o] + sum over the nine taps inside the image of
  * t[p + (ky-1) w + (kx-1)][(ky*3+kx)*4 + o], taps in ky-major order.  The update block's flow head (256 -> 4) costs nine
  * times fewer MFMA steps this way than as a 3x3 convolution padded to a 32-column tile.  t: [n*h*w][ld_t] f32 (ld_t >= 36,
- * multiple of 4, 16-byte aligned rows), bias: 4 floats or NULL, out: [n*h*w][4] f32. */
-int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, void* stream);
+ * multiple of 4, 16-byte aligned rows), bias: 4 floats or NULL, out: [n*h*w][4] f32.  parts (1..4): t is that many such maps
+ * part_stride floats apart (a multiple of 4) whose sum is meant - the partial maps of vfml_conv_desc.proj_out; per tap they
+ * are added in order, map 0 first. */
+int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, int parts, int64_t part_stride,
+                   void* stream);
 
 /* coords1 += delta (4 floats per pixel: fwd x,y, bwd x,y); flow = coords1 - grid is written to
  * flow_a[p*ld_a..+4] and flow_b[p*ld_b..+4] (either may be NULL).  h,w give the pixel grid,

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), f"{n} declared in include/vfml.h but not exported"
     assert sorted(hip.EXPORTS) == names
     lib.vfml_abi_version.restype = ctypes.c_int
-    assert lib.vfml_abi_version() == 24
+    assert lib.vfml_abi_version() == 25
 
 
 def test_argument_validation_needs_no_gpu():
@@ -50,10 +50,10 @@ def test_conv_desc_layout_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        m = re.match(r"(const float\*|float\*|double\*|int32_t|float)\s+(.*)", decl)
+        m = re.match(r"(const float\*|const void\*|float\*|double\*|int32_t|float)\s+(.*)", decl)
         for name in m.group(2).split(","):
             fields.append((name.strip(), m.group(1)))
-    want = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "double*": ctypes.c_void_p, "int32_t": ctypes.c_int32,
+    want = {"const float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "double*": ctypes.c_void_p, "int32_t": ctypes.c_int32,
             "float": ctypes.c_float}
     assert [(n, want[t]) for n, t in fields] == list(hip.ConvDesc._fields_)
 

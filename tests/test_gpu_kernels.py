@@ -989,6 +989,64 @@ def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
         hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)
 
 
+@pytest.mark.parametrize("n,H,W,tile", [(3, 135, 240, None), (1, 17, 23, "3,2,2,2"), (2, 9, 14, "2,2,2,2")])
+def test_projection_epilogue_is_the_two_layer_flow_head(gpu, monkeypatch, n, H, W, tile):
+    """vfml_conv_desc.proj_out: conv 3x3 (128 -> 256) + ReLU + 1x1 (256 -> 36) in one launch - the partial maps of the two
+    128-column tiles add up to what the two launches give (same products, another order of the last additions) and to the
+    float64 result; through the tap sum: the 3x3 -> 4-channel flow head.  Ragged sizes on both tile shapes; nothing is
+    written outside the partial maps; the route refuses what it is not built for."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(H * W + n)
+    cin, cmid = 128, 256
+    x = torch.randn(n, cin, H, W, generator=g)
+    w1 = torch.randn(cmid, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b1 = torch.randn(cmid, generator=g) * 0.1
+    w2 = torch.randn(4, cmid, 3, 3, generator=g) / math.sqrt(cmid * 9)
+    b2 = torch.randn(4, generator=g)
+    ref = F.conv2d(F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1)), w2.double(), b2.double(), padding=1).float()
+    P = n * H * W
+    LD = 768
+    buf = torch.zeros(P * LD, device=gpu)
+    hip.to_s16(nhwc(x), P, cin, cin, buf, LD, dst_off=256)
+    W1 = as_weight(pack_conv_weight(w1, cblock=True), cmid, "f16x3", order=hip.KORDER_CBLOCK)
+    W2 = as_weight(w2.permute(2, 3, 0, 1).reshape(36, cmid), 36, "f16x3", order=hip.KORDER_CBLOCK)
+    if tile:
+        monkeypatch.setenv("VFML_DMA_TILE", tile)
+    # two launches
+    fh = torch.zeros(P * cmid, device=gpu)
+    hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh, cmid, in0_off=256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+               in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16)
+    taps = torch.zeros(P * 36, device=gpu)
+    if tile:
+        monkeypatch.delenv("VFML_DMA_TILE")
+    hip.conv2d(fh, cmid, cmid, n, H, W, W2, None, 36, 1, 1, taps, 36, in_fmt=hip.FMT_S16)
+    two = torch.empty(P * 4, device=gpu)
+    hip.tapsum3x3(taps, 36, b2.cuda(), n, H, W, two)
+    # one launch
+    if tile:
+        monkeypatch.setenv("VFML_DMA_TILE", tile)
+    parts = torch.full((2 * P * 36 + 64,), float("nan"), device=gpu)
+    fh2 = torch.full((P * cmid,), 7.0, device=gpu)
+    hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh2, cmid, in0_off=256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+               in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36)
+    assert torch.isnan(parts[2 * P * 36:]).all() and torch.isfinite(parts[:2 * P * 36]).all()
+    assert (fh2 == 7.0).all()                      # the 256-channel map is not stored
+    one = torch.empty(P * 4, device=gpu)
+    hip.tapsum3x3(parts, 36, b2.cuda(), n, H, W, one, parts=2, part_stride=P * 36)
+    psum = (parts[:P * 36] + parts[P * 36:2 * P * 36]).cpu()
+    assert rel_err(psum, taps.cpu()) < 2e-6, rel_err(psum, taps.cpu())
+    got1, got2 = from_nhwc(one, n, H, W, 4), from_nhwc(two, n, H, W, 4)
+    assert rel_err(got1, got2) < 2e-6
+    assert rel_err(got1, ref) < CONV_TOL["f16x3"], rel_err(got1, ref)
+    with pytest.raises(RuntimeError, match="proj_out"):        # reduced products are not built with it
+        hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh2, cmid, in0_off=256, pad_h=1, pad_w=1,
+                   epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36, mfma="2a")
+    with pytest.raises(RuntimeError, match="proj_out"):        # nor another epilogue
+        hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh2, cmid, in0_off=256, pad_h=1, pad_w=1,
+                   in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36)
+
+
 def _as_f32_storage(half_tensor):
     """A float16 tensor's bytes as the float32 buffer the ctypes wrappers take (even element count)."""
     return half_tensor.contiguous().view(torch.float32)

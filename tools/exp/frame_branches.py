@@ -28,6 +28,8 @@ LAYERS = [("convc1", 672, 256, 1, 1, 3), ("convc2", 256, 192, 3, 3, 3), ("conv",
           ("fh1", 128, 256, 3, 3, 3), ("fh2", 256, 36, 1, 1, 3)]
 if os.environ.get("FB_SWEEP1X1", "0") == "1":      # what bounds the 1x1 motion-encoder layer: columns (MFMA work) or rows (bytes)?
     LAYERS = [(f"k{k}n{n}", k, n, 1, 1, 3) for k in (352, 672) for n in (64, 128, 192, 256)]
+if os.environ.get("FB_ONLY", ""):
+    LAYERS = [l for l in LAYERS if l[0] in os.environ["FB_ONLY"].split(",")]
 if os.environ.get("FB_ONLY1X1", "0") == "1":
     LAYERS = [l for l in LAYERS if l[3] * l[4] == 1]
 if os.environ.get("FB_ONLY3", "0") == "1":
@@ -51,11 +53,21 @@ bias = torch.randn(256, device=dev)
 W = [weight(*l[1:]) for l in LAYERS]
 
 
+PROJ = os.environ.get("FB_PROJ", "0") == "1"       # fh1 with the projection epilogue (vfml_conv_desc.proj_out) instead of its store
+if PROJ:
+    w36 = torch.randn(36 * 256, device=dev) / 48.0
+    W36 = hip.SplitWeight(36, 256, dev).fill(w36, scale=hip.SplitWeight.auto_scale(float(w36.abs().max())))
+    W36.order = hip.KORDER_CBLOCK
+    parts = torch.empty(2 * NF * P * 36, device=dev)
+
+
 def chain(f0, nf, iters):
     for _ in range(iters):
         for (name, cin, cout, kh, kw, mfma), w, o in zip(LAYERS, W, outs):
+            kw_ = dict(proj=W36, proj_out=parts, ld_proj=36) if PROJ and name == "fh1" else {}
             hip.conv2d(src, cin, LD, nf, H8, W8, w, bias, cout, kh, kw, o, 256, in0_off=f0 * P * LD, out_off=f0 * P * 256,
-                       pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, mfma=mfma)
+                       pad_h=kh // 2, pad_w=kw // 2, epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, mfma=mfma,
+                       **kw_)
 
 
 side = [torch.cuda.Stream() for _ in range(NF - 1)]

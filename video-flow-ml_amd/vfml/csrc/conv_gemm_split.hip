@@ -773,6 +773,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       const int bc = cur_n0 + wn * (32 * TN) + (lane % (8 * TN)) * 4;
       if (bc < a.cout) bv = *reinterpret_cast<const f32x4*>(a.bias + bc);
     }
+    // (projection epilogue: the tile's slice of the second weight is requested here and waits in 24 registers for the K
+    // loop's stages to become free - requested behind the K loop, its round trip was exposed once per tile)
+    constexpr bool PROJ = !PERSIST && MF16 && FASTK && NM == 3 && TBN == 128 && WM == 2 && NW == 4;   // vfml_conv_desc.proj_out
+    u32x4 pw[PROJ_PIECES];      // (dead where PROJ is false)
+    if constexpr (PROJ) {
+      if (a.proj_out) proj_weights_load(a, cur_n0, t, pw);
+    }
     for (int kt = 0; kt < nk - 2; kt += 2) step_pair(kt, false, next);
     step_pair(nk - 2, true, next);
 
@@ -903,6 +910,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
       static_for<TM>([&](auto slab) {       // (static_for, not `#pragma unroll`: the body is large and a slab loop left rolled
         constexpr int i = decltype(slab)::value;   // would index the accumulators dynamically - scratch)
         __syncthreads();     // every wave is done with the stage buffers / with the previous slab
+        if constexpr (PROJ && i == 0) {
+          if (a.proj_out) proj_weights_store(pw, smem_raw + proj_lds_off<TBN>(), t);
+        }
         if constexpr (MF16) {
           // 16 x 16 tiles: a lane's quad = pixel row lane & 15, output channels 4 (lane >> 4) .. + 3; block row i = tile
           // rows 2i, 2i + 1 (i is the index of the enclosing slab loop: a compile-time constant through static_for)
@@ -926,8 +936,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
           }
         }
         __syncthreads();
+        bool projected = false;
+        if constexpr (PROJ) {
+          if (a.proj_out) {      // (host: ReLU, no addend; the 256-channel map itself is not stored)
+            epilogue_proj_slab<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
+            projected = true;
+          }
+        }
         // (what the fast rows take, the 16x16x32 forms have already written straight from their accumulators)
-        if (!epilogue_rows_fast<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32))
+        if (!projected && !epilogue_rows_fast<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32))
           epilogue_rows<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
         if (a.stats_part) {
           // instance-norm statistics of the slab while it is in LDS (vfml_conv_desc.stats_part, split-row sources): the
@@ -1503,6 +1520,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   const bool fits_one = (e0 > e1 ? e0 : e1) * 4 < (1ll << 31) && (int64_t)d->n * d->h * d->w * d->ld0 * 4 < (1ll << 30);
   a.bytes0 = fits_one ? (int)((e0 > e1 ? e0 : e1) * 4) : 0;
   a.tilebase = 0;
+  a.proj_w = nullptr; a.proj_lo_off = a.proj_bytes = a.proj_n = a.proj_kp = 0; a.proj_inv = 1.f; a.proj_out = nullptr; a.ld_proj = 0;
   a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo; a.bias = d->bias;
   a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
   a.addend = d->addend; a.ld_addend = d->ld_addend;
@@ -1614,6 +1632,26 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
           a.out_t_k1 = d->ksplit_ws + (int64_t)a.M * d->ldo;
         }
       }
+      if (d->proj_out) {
+        // projection epilogue: what the kernel's slab routine is built for
+        VFML_REQUIRE(d->epilogue == VFML_EPI_RELU && !d->addend && !d->stats_part && !d->out_t && !a.direct,
+                     "vfml_conv2d_split: proj_out goes with VFML_EPI_RELU, no addend / stats_part / out_t");
+        VFML_REQUIRE(a.fastk && a.nm == 3 && d->cout % 128 == 0,
+                     "vfml_conv2d_split: proj_out needs the uniform-step loader (channel-block weight order, whole 32-channel "
+                     "blocks), the full split product and cout %% 128 == 0");
+        VFML_REQUIRE(d->proj_hi && d->proj_lo && d->proj_n > 0 && d->proj_n <= 48 && d->proj_n % 4 == 0 && d->proj_kp >= d->cout &&
+                         d->proj_kp % 8 == 0 && d->ld_proj >= d->proj_n && d->ld_proj % 4 == 0 && vfml_aligned16(d->proj_out) &&
+                         vfml_aligned16(d->proj_hi) && vfml_aligned16(d->proj_lo) && d->proj_scale > 0.f,
+                     "vfml_conv2d_split: proj_hi / proj_lo [proj_n <= 48, %% 4 == 0][proj_kp >= cout] f16 planes, ld_proj >= proj_n, "
+                     "16-byte alignment");
+        const char* ph2 = (const char*)d->proj_hi;
+        const char* pl2 = (const char*)d->proj_lo;
+        const int64_t plane = (int64_t)d->proj_n * d->proj_kp * 2;
+        VFML_REQUIRE(pl2 >= ph2 && (pl2 - ph2) + plane < (1ll << 30), "vfml_conv2d_split: proj_lo must follow proj_hi within 1 GiB");
+        a.proj_w = ph2; a.proj_lo_off = (int)(pl2 - ph2); a.proj_bytes = (int)((pl2 - ph2) + plane);
+        a.proj_n = d->proj_n; a.proj_kp = d->proj_kp; a.proj_inv = 1.0f / d->proj_scale;
+        a.proj_out = d->proj_out; a.ld_proj = d->ld_proj;
+      }
       const char* tile_env = getenv("VFML_DMA_TILE");   // experiments / tests: "TM,TN,WM,WN" (read per call)
       int cfg = d->cout > 32 ? 2122 : 1141;
       if (d->cout > 64) {
@@ -1633,6 +1671,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         if (c2322 < best) { best = c2322; cfg = 2322; }
         if (c2222 < best) { best = c2222; cfg = 2222; }
         if (c2122 < best) { best = c2122; cfg = 2122; }
+        if (a.proj_out && cfg != 3222 && cfg != 2222) cfg = c3222 <= c2222 ? 3222 : 2222;    // (128-column tiles of four waves)
       }
       bool forced = false;
       if (tile_env && d->cout > 32) {
@@ -1641,11 +1680,12 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         const int want = tm * 1000 + tn * 100 + wm * 10 + wn;
         // (2241 / 2341 exist in the shared-stage kernel only; narrower outputs keep their per-tap shapes otherwise)
         if (d->cout > 64 || want == 2241 || want == 2341) { cfg = want; forced = true; }
+        VFML_REQUIRE(!a.proj_out || cfg == 3222 || cfg == 2222, "vfml_conv2d_split: proj_out runs on the 192 x 128 / 128 x 128 tiles (VFML_DMA_TILE)");
       }
       // stride-1 "same" convolutions with a filter row of 2..5 taps: one activation stage per (channel block, tap row),
       // shared by the row's taps (conv_gemm_tapx.hip; VFML_TAPX=0: the per-tap stages of conv_gemm_dma_kernel, for A/B)
       static const int tapx = getenv("VFML_TAPX") ? atoi(getenv("VFML_TAPX")) : 1;
-      if (tapx && !(d->flags & VFML_CONV_PER_TAP)) {
+      if (tapx && !(d->flags & VFML_CONV_PER_TAP) && !a.proj_out) {
         // (VFML_TAPX=2: also the three-MFMA calls on the 192 x 128 / 128 x 192 tiles, where the two kernels run level)
         const int tcfg = vfml_detail::tapx_cfg(a, cfg, forced);
         if (tcfg && (tapx >= 2 || forced || a.nm == 5 || tcfg == 2241 || tcfg == 2341)) return vfml_detail::launch_tapx(a, tcfg, s);
@@ -1676,6 +1716,7 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
     vfml_set_error("vfml_conv2d_split: split-row sources need w_hi and w_lo within 1 GiB of each other (one allocation)");
     return 1;
   }
+  VFML_REQUIRE(!d->proj_out, "vfml_conv2d_split: proj_out is implemented for split-row (VFML_FMT_S16) sources only");
   if (bn == 128) {
     a.ntiles = (d->cout + 127) / 128;
     return bigc ? launch<128, 2, 2, true, false>(a, s) : launch<128, 2, 2, false, false>(a, s);

@@ -43,6 +43,9 @@ struct SplitArgs {
   int nm;                       // terms of the split product: 3 all, 2 weights as plain f16, 4 activations as plain f16, 1 both
   int fast_epi;                 // 0: the general epilogue routine everywhere (VFML_FAST_EPI=0, A/B)
   int ksplit; float* out_k1; float* out_t_k1;   // persistent GEMM form: 2 = two work items per tile, one per half of K; the second half's sums go to out_k1 (out_t_k1)
+  // projection epilogue (vfml_conv_desc.proj_*): relu(out) is not stored but multiplied, per 128-column tile, by that
+  // tile's slice of a second [proj_n][cout] weight (two f16 planes, lo plane proj_lo_off bytes behind the hi plane)
+  const char* proj_w; int proj_lo_off, proj_bytes, proj_n, proj_kp; float proj_inv; float* proj_out; int ld_proj;
 };
 // conv_gemm_tapx.hip: the kernel that shares one activation stage between the taps of a filter row
 #define VFML_TAPX_KWMAX 5      // widest filter row it is built for
@@ -334,6 +337,111 @@ __device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const f
   }
 }
 
+// workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every outstanding global store
+// (vmcnt(0)), which serialises an epilogue's slabs on the store round trip
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// Projection epilogue (include/vfml.h vfml_conv_desc.proj_out; the flow head: 3x3 to 256 channels, ReLU, then 256 -> 4 over
+// 3x3 run as a 1x1 to 36 tap-major columns).  A 64-row slab of the workgroup's fp32 tile is in LDS (sC, row stride BN + 4
+// floats, BN = 128): every (row, 8-channel unit) becomes relu((acc * w_inv + bias) * out_scale) as 16 bytes of hi halves
+// + 16 bytes of lo halves IN PLACE (the unit's own 32 bytes - exactly what a split-row store would have written to HBM);
+// then wave w multiplies rows 16 w .. 16 w + 15 by the tile's 128-channel slice of the projection weights on the matrix
+// cores (the full split product, 16x16x32 MFMAs, weight fragments from the copy proj_weights_store left behind the slab) and
+// stores the [16][proj_n] partial sums of this column tile.  The 256-channel map never travels to HBM and back.
+// The tile's slice of the projection weights - 48 rows (those past proj_n zero) x 128 channels x {hi, lo} = 24 KB - goes to
+// LDS once per tile, behind the slab (rows of 256 + 16 bytes: conflict-free fragment reads): requested into registers
+// before the slab loop (proj_weights_load), written once the K loop's stages are free (proj_weights_store).
+constexpr int PROJ_ROW = 272, PROJ_ROWS = 48, PROJ_PIECES = 2 * PROJ_ROWS * 16 / 256;
+template <int BN>
+constexpr int proj_lds_off() { return 64 * (BN + 4) * 4; }
+__device__ __forceinline__ void proj_weights_load(const SplitArgs& a, int n0, int t, u32x4 (&pw)[PROJ_PIECES]) {
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.proj_w), 0, a.proj_bytes, 0x00020000);
+  static_for<PROJ_PIECES>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int q = t + 256 * k, plane = q / (PROJ_ROWS * 16), rem = q % (PROJ_ROWS * 16), n = rem >> 4, seg = rem & 15;
+    const int off = n < a.proj_n ? (n * a.proj_kp + n0) * 2 + seg * 16 : (int)0x40000000;
+    pw[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, plane ? a.proj_lo_off : 0, 0));
+  });
+}
+__device__ __forceinline__ void proj_weights_store(const u32x4 (&pw)[PROJ_PIECES], char* lds, int t) {
+  static_for<PROJ_PIECES>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int q = t + 256 * k, plane = q / (PROJ_ROWS * 16), rem = q % (PROJ_ROWS * 16), n = rem >> 4, seg = rem & 15;
+    *reinterpret_cast<u32x4*>(lds + (plane * PROJ_ROWS + n) * PROJ_ROW + seg * 16) = pw[k];
+  });
+}
+
+template <int BN, int NT>
+__device__ __forceinline__ void epilogue_proj_slab(const SplitArgs& a, float* sC, int m0, int n0, int t, int nrows, int rstride,
+                                                   int roff) {
+  static_assert(BN == 128 && NT == 256, "projection epilogue: 128-column tiles of four waves");
+  constexpr int LDC = BN + 4, C8 = BN / 8, RPP = NT / C8;
+  const int c8 = t % C8;
+  const int gcol = n0 + c8 * 8;
+  f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (a.bias && gcol < a.cout) {
+    bias4[0] = *reinterpret_cast<const f32x4*>(a.bias + gcol);
+    bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + gcol + 4);
+  }
+  for (int row = t / C8; row < nrows; row += RPP) {
+    float* u = &sC[row * LDC + c8 * 8];
+    f32x4 v[2] = {*reinterpret_cast<const f32x4*>(u), *reinterpret_cast<const f32x4*>(u + 4)};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] = fmaxf((v[q][e] * a.w_inv + bias4[q][e]) * a.out_scale, 0.f);
+    if (gcol >= a.cout) v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    U8 hi, lo;
+    split4(v[0], hi, lo, 0);
+    split4(v[1], hi, lo, 4);
+    *reinterpret_cast<h16x8*>(u) = hi.v;
+    *reinterpret_cast<h16x8*>(u + 4) = lo.v;
+  }
+  lds_barrier();
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 d[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const char* arow = reinterpret_cast<const char*>(sC) + (16 * wave + r) * (LDC * 4) + g * 32;
+  const char* brow = reinterpret_cast<const char*>(sC) + proj_lds_off<BN>() + r * PROJ_ROW + g * 16;
+  static_for<4>([&](auto sc) {
+    constexpr int ks = decltype(sc)::value;            // 32 channels of the tile per step
+    h16x8 bh[3], bl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      bh[j] = *reinterpret_cast<const h16x8*>(brow + 16 * j * PROJ_ROW + ks * 64);
+      bl[j] = *reinterpret_cast<const h16x8*>(brow + (PROJ_ROWS + 16 * j) * PROJ_ROW + ks * 64);
+    }
+    const h16x8 ah = *reinterpret_cast<const h16x8*>(arow + ks * 128);
+    const h16x8 al = *reinterpret_cast<const h16x8*>(arow + ks * 128 + 16);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, d[j], 0, 0, 0);
+      d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, d[j], 0, 0, 0);
+      d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, d[j], 0, 0, 0);
+    }
+  });
+  // lane: pixel row r of the wave's 16, projection columns 16 j + 4 g .. + 3
+  const int srow = 16 * wave + r;
+  const int grow = m0 + (srow >> 5) * rstride + roff + (srow & 31);
+  if (srow < nrows && grow < a.M) {
+    float* o = a.proj_out + ((int64_t)(n0 / BN) * a.M + grow) * a.ld_proj;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int n = 16 * j + 4 * g;
+      if (n < a.proj_n) {
+        f32x4 v = d[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= a.proj_inv;
+        *reinterpret_cast<f32x4*>(o + n) = v;
+      }
+    }
+  }
+}
+
 template <int BN, int NT>
 __device__ __forceinline__ bool epilogue_rows_fast(const SplitArgs& a, const float* sC, int m0, int n0, int t, int nrows,
                                                    int rstride, int roff) {
@@ -358,14 +466,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff_byte
 #if defined(__HIP_DEVICE_COMPILE__)
   // address = base + voffset + soffset; only voffset is range-checked (an out-of-range lane writes zeros)
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff_bytes, soff_bytes, 0, 0);
-#endif
-}
-
-// workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every outstanding global store
-// (vmcnt(0)), which serialises an epilogue's slabs on the store round trip
-__device__ __forceinline__ void lds_barrier() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
 

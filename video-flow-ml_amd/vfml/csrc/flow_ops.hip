@@ -321,7 +321,7 @@ __global__ void flow_rows7_kernel(const f32x4* __restrict__ flow, int w, int64_t
 
 // out[p] = bias + sum of the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3)
 __global__ void tapsum3x3_kernel(const float* __restrict__ t, int ld, const float* __restrict__ bias, int h, int w,
-                                 int64_t total, f32x4* __restrict__ out) {
+                                 int64_t total, f32x4* __restrict__ out, int parts, int64_t part_stride) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
     const int x = (int)(p % w), y = (int)((p / w) % h);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -331,8 +331,12 @@ __global__ void tapsum3x3_kernel(const float* __restrict__ t, int ld, const floa
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int yy = y + ky - 1, xx = x + kx - 1;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w)
-          s = s + *reinterpret_cast<const f32x4*>(t + (p + (int64_t)(ky - 1) * w + (kx - 1)) * ld + (ky * 3 + kx) * 4);
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+          const float* q = t + (p + (int64_t)(ky - 1) * w + (kx - 1)) * ld + (ky * 3 + kx) * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(q);
+          for (int k = 1; k < parts; ++k) v = v + *reinterpret_cast<const f32x4*>(q + k * part_stride);
+          s = s + v;
+        }
       }
     out[p] = s;
   }
@@ -665,13 +669,16 @@ extern "C" int vfml_flow_rows7(const float* flow, int n, int h, int w, float* ro
   return vfml_check_launch("vfml_flow_rows7");
 }
 
-extern "C" int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, void* stream) {
+extern "C" int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, int parts,
+                              int64_t part_stride, void* stream) {
   VFML_REQUIRE(t && out && n > 0 && h > 0 && w > 0, "vfml_tapsum3x3: bad argument");
+  VFML_REQUIRE(parts >= 1 && parts <= 4 && (parts == 1 || (part_stride > 0 && part_stride % 4 == 0)),
+               "vfml_tapsum3x3: parts in 1..4, part_stride a positive multiple of 4 floats");
   VFML_REQUIRE(ld_t >= 36 && ld_t % 4 == 0 && vfml_aligned16(t) && vfml_aligned16(out),
                "vfml_tapsum3x3: ld_t must be a multiple of 4 and >= 36, t and out 16-byte aligned");
   const int64_t total = (int64_t)n * h * w;
   hipLaunchKernelGGL(tapsum3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
-                     ld_t, bias, h, w, total, (f32x4*)out);
+                     ld_t, bias, h, w, total, (f32x4*)out, parts, part_stride);
   return vfml_check_launch("vfml_tapsum3x3");
 }
 

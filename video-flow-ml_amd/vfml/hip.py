@@ -51,6 +51,8 @@ class ConvDesc(ctypes.Structure):
         ("flags", c_int32),
         ("stats_part", c_void_p),
         ("ksplit_ws", c_void_p),
+        ("proj_hi", c_void_p), ("proj_lo", c_void_p), ("proj_n", c_int32), ("proj_kp", c_int32), ("proj_scale", c_float),
+        ("proj_out", c_void_p), ("ld_proj", c_int32),
     ]
 
 
@@ -143,7 +145,7 @@ def lib():
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_flow_rows7.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
-    L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]
     L.vfml_coords_update.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_int, c_void_p]
     L.vfml_flow_lod.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
@@ -155,7 +157,7 @@ def lib():
     L.vfml_convex_upsample.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = header/library drift
-    if L.vfml_abi_version() != 24:
+    if L.vfml_abi_version() != 25:
         raise RuntimeError("libvfml_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -331,11 +333,14 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            in0_off=0, weight_off=0, in1=None, c1=0, ld1=0, in1_off=0, out_off=0, epilogue=EPI_NONE, split=0, out_scale=1.0,
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
-           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3, per_tap=False, ksplit_ws=None):
+           out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3, per_tap=False, ksplit_ws=None,
+           proj=None, proj_out=None, ld_proj=0):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers).  mfma: terms of the split-f16 product (3; 2 or "2w" = weights as plain
     f16; "2a" = activations as plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA2A / _MFMA1).  per_tap:
-    VFML_CONV_PER_TAP (the per-tap staging kernel where the shared-stage one would run; same bits)."""
+    VFML_CONV_PER_TAP (the per-tap staging kernel where the shared-stage one would run; same bits).
+    proj (a SplitWeight [proj_n <= 48][cout]) with proj_out / ld_proj: the projection epilogue (vfml_conv_desc.proj_out) -
+    relu(out) is not stored, proj_out receives cout / 128 partial maps [n*ho*wo][ld_proj] of relu(out) x proj^T."""
     d = ConvDesc()
     d.in0, d.c0, d.ld0 = _ptr(_dev(in0), in0_off), c0, ld0
     d.in1, d.c1, d.ld1 = (_ptr(_dev(in1), in1_off) if in1 is not None else None), c1, ld1
@@ -357,6 +362,12 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, "2a": CONV_MFMA2A, 1: CONV_MFMA1}[mfma] | (CONV_PER_TAP if per_tap else 0)
     d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
     d.ksplit_ws = _ptr(_dev(ksplit_ws)) if ksplit_ws is not None else None      # GEMM form: second half of K (vfml.h)
+    if proj is not None:
+        if not isinstance(proj, SplitWeight) or proj.lo is None or proj_out is None:
+            raise ValueError("proj: a SplitWeight with both planes, and proj_out")
+        d.proj_hi, d.proj_lo = c_void_p(proj.hi.data_ptr()), c_void_p(proj.lo.data_ptr())
+        d.proj_n, d.proj_kp, d.proj_scale = proj.rows, proj.kp, proj.scale
+        d.proj_out, d.ld_proj = _ptr(_dev(proj_out)), ld_proj
     if is_split:
         # weight_off counts rows of the split planes (each row kp halves)
         def launch():
@@ -396,11 +407,11 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     _PROFILE.append((conv_variant(max(cout, 1024) if out_fmt == FMT_F16 else cout, is_split, ctot, in_fmt == FMT_S16, n * ho * wo,
                                   weight.order if is_split else KORDER_TAP, plain, fastk, swap_cross, nm_eff, same, per_tap,
                                   h16=out_fmt == FMT_F16),
-                     2.0 * n * ho * wo * kh * kw * (c0 + c1) * cout,
+                     2.0 * n * ho * wo * (kh * kw * (c0 + c1) * cout + (cout * proj.rows if proj is not None else 0)),
                      # operands read once + result written once, 4 bytes per element in either activation format
                      4.0 * (n * h * w * (c0 + c1) + n * ho * wo * cout * (2 if out_t is not None else 1)
                             + cout * kh * kw * (c0 + c1) * (0.5 if is_split and weight.lo is None else 1.0)), e0, e1,
-                     f"{kh}x{kw} {c0 + c1}->{cout}"))
+                     f"{kh}x{kw} {c0 + c1}->{cout}" + (f"->{proj.rows}" if proj is not None else "")))
 
 
 def frames_to_nhwc4(src, n, H, W, scale, shift, dst):
@@ -610,10 +621,11 @@ def flow_rows7(flow, n, h, w, rows):
     _check(lib().vfml_flow_rows7(_ptr(_dev(flow)), n, h, w, _ptr(_dev(rows)), _stream()), "vfml_flow_rows7")
 
 
-def tapsum3x3(t, ld_t, bias, n, h, w, out):
-    """out[p][0:4] = bias + the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3)."""
+def tapsum3x3(t, ld_t, bias, n, h, w, out, parts=1, part_stride=0):
+    """out[p][0:4] = bias + the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3); parts > 1: t is
+    that many maps part_stride floats apart whose sum is meant (conv2d(..., proj_out=))."""
     _check(lib().vfml_tapsum3x3(_ptr(_dev(t)), ld_t, _ptr(bias) if bias is not None else None, n, h, w, _ptr(_dev(out)),
-                                _stream()), "vfml_tapsum3x3")
+                                parts, part_stride, _stream()), "vfml_tapsum3x3")
 
 
 def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None, ld_b=0, flow_b_off=0,

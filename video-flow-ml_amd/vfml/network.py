@@ -845,7 +845,7 @@ class MOFNetHIP(_Holder):
             fh = self._buf("fh", MP * 256, dev)
             flow4 = self._buf("flow4", MP * 4, dev)
             delta = self._buf("delta", MP * 4, dev)
-            fh_taps = self._buf("fh_taps", MP * 36, dev)
+            fh_taps = self._buf("fh_taps", 2 * MP * 36, dev)     # (two partial maps with the fused flow head)
             frows = self._buf("flow_rows7", MP * 32, dev)
             coords1 = self._buf("coords1", MP * 4, dev)
 
@@ -874,6 +874,8 @@ class MOFNetHIP(_Holder):
                     branch = self._side2.get(dev)
                     if branch is None:
                         branch = self._side2[dev] = torch.cuda.Stream(device=dev)
+                # (A/B switch: VFML_FUSE_HEAD=0 runs the flow head's two layers as two launches)
+                fuse_head = os.environ.get("VFML_FUSE_HEAD", "1") != "0" and AF == hip.FMT_S16
                 for it in range(cfg.decoder_depth):
                     # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
                     # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
@@ -955,6 +957,16 @@ class MOFNetHIP(_Holder):
                                    in_fmt=AF, out_fmt=AF, aux_fmt=AF, mfma=mf(f"{ub}.gru.convq{k}.iter"))
                     # flow head
                     wgt, b = P[f"{ub}.flow_head.conv1"]
+                    wgt2, b2 = P[f"{ub}.flow_head.conv2"]
+                    if (self._tapsum and fuse_head and mf(f"{ub}.flow_head.conv1") == 3 and mf(f"{ub}.flow_head.conv2") == 3):
+                        # both layers in ONE launch (vfml_conv_desc.proj_out): the 256-channel map stays in LDS, the launch
+                        # leaves two partial 36-column maps (one per 128-channel half) that the tap sum adds
+                        hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
+                                   epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=3, proj=wgt2, proj_out=fh_taps, ld_proj=36)
+                        hip.tapsum3x3(fh_taps, 36, b2, ng, h, w, delta, parts=2, part_stride=ng * Pn * 36)
+                        hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                                          flow_b_off=MF + 124, fmt_b=AF)
+                        continue
                     hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.flow_head.conv1"))
                     wgt, b = P[f"{ub}.flow_head.conv2"]
@@ -986,7 +998,7 @@ class MOFNetHIP(_Holder):
                                                 up_fixed, out_off=(d * M + c) * H * W * 2)
 
             gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(), vol16,
-                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"))
+                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"), os.environ.get("VFML_FUSE_HEAD", "1"))
             self._pre_body = torch.cuda.Event()
             self._pre_body.record(torch.cuda.current_stream(dev))      # (what a prefetch of the next window waits for)
             self._run_body(body, gkey, dev)
