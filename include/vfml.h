@@ -104,7 +104,7 @@ typedef struct vfml_conv_desc {
          proj_out[t][p][j] = sum_{c in 128 t .. 128 t + 127} relu(out[p][c]) * proj_w[j][c],   j < proj_n <= 48,
      proj_out = [cout / 128][n*ho*wo][ld_proj] floats; the caller adds the cout / 128 maps (vfml_tapsum3x3 does).  proj_hi /
      proj_lo: the f16 planes [proj_n][proj_kp] of proj_w * proj_scale (vfml_split_f16; lo behind hi within 1 GiB), three
-     MFMAs per product.  The flow head - 3x3 to 256 channels, ReLU, 256 -> 4 over 3x3 as a 1x1 to 36 tap-major columns -
+     MFMAs per product (with VFML_CONV_MFMA2A two, in the projection as in the convolution: relu(out) as plain f16).  The flow head - 3x3 to 256 channels, ReLU, 256 -> 4 over 3x3 as a 1x1 to 36 tap-major columns -
      as ONE launch whose 256-channel map never travels to HBM and back.  Replaces: the second cuDNN conv of
      FlowHead. */
   const void* proj_hi; const void* proj_lo; int32_t proj_n; int32_t proj_kp; float proj_scale;

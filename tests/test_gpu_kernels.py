@@ -1039,9 +1039,21 @@ def test_projection_epilogue_is_the_two_layer_flow_head(gpu, monkeypatch, n, H, 
     got1, got2 = from_nhwc(one, n, H, W, 4), from_nhwc(two, n, H, W, 4)
     assert rel_err(got1, got2) < 2e-6
     assert rel_err(got1, ref) < CONV_TOL["f16x3"], rel_err(got1, ref)
-    with pytest.raises(RuntimeError, match="proj_out"):        # reduced products are not built with it
+    # "2a" (activations as plain f16, in the projection as in the convolution) against its own two launches
+    hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh, cmid, in0_off=256, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+               in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, mfma="2a")
+    if tile:
+        monkeypatch.delenv("VFML_DMA_TILE")
+    hip.conv2d(fh, cmid, cmid, n, H, W, W2, None, 36, 1, 1, taps, 36, in_fmt=hip.FMT_S16, mfma="2a")
+    if tile:
+        monkeypatch.setenv("VFML_DMA_TILE", tile)
+    hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh2, cmid, in0_off=256, pad_h=1, pad_w=1,
+               epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36, mfma="2a")
+    psum = (parts[:P * 36] + parts[P * 36:2 * P * 36]).cpu()
+    assert rel_err(psum, taps.cpu()) < 2e-6, rel_err(psum, taps.cpu())
+    with pytest.raises(RuntimeError, match="proj_out"):        # the other reduced products are not built with it
         hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh2, cmid, in0_off=256, pad_h=1, pad_w=1,
-                   epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36, mfma="2a")
+                   epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36, mfma=1)
     with pytest.raises(RuntimeError, match="proj_out"):        # nor another epilogue
         hip.conv2d(buf, cin, LD, n, H, W, W1, b1.cuda(), cmid, 3, 3, fh2, cmid, in0_off=256, pad_h=1, pad_w=1,
                    in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, proj=W2, proj_out=parts, ld_proj=36)

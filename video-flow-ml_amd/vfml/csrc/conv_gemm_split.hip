@@ -775,7 +775,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
     }
     // (projection epilogue: the tile's slice of the second weight is requested here and waits in 24 registers for the K
     // loop's stages to become free - requested behind the K loop, its round trip was exposed once per tile)
-    constexpr bool PROJ = !PERSIST && MF16 && FASTK && NM == 3 && TBN == 128 && WM == 2 && NW == 4;   // vfml_conv_desc.proj_out
+    constexpr bool PROJ = !PERSIST && MF16 && FASTK && (NM == 3 || NM == 4) && TBN == 128 && WM == 2 && NW == 4;   // vfml_conv_desc.proj_out
     u32x4 pw[PROJ_PIECES];      // (dead where PROJ is false)
     if constexpr (PROJ) {
       if (a.proj_out) proj_weights_load(a, cur_n0, t, pw);
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_gem
         bool projected = false;
         if constexpr (PROJ) {
           if (a.proj_out) {      // (host: ReLU, no addend; the 256-channel map itself is not stored)
-            epilogue_proj_slab<TBN, NT>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
+            epilogue_proj_slab<TBN, NT, NM == 4>(a, sC, cur_m0, cur_n0, t, WM * 32, 32 * TM, i * 32);
             projected = true;
           }
         }
@@ -1636,9 +1636,10 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
         // projection epilogue: what the kernel's slab routine is built for
         VFML_REQUIRE(d->epilogue == VFML_EPI_RELU && !d->addend && !d->stats_part && !d->out_t && !a.direct,
                      "vfml_conv2d_split: proj_out goes with VFML_EPI_RELU, no addend / stats_part / out_t");
-        VFML_REQUIRE(a.fastk && a.nm == 3 && d->cout % 128 == 0,
+        VFML_REQUIRE(a.fastk && (a.nm == 3 || a.nm == 4) && d->cout % 128 == 0,
                      "vfml_conv2d_split: proj_out needs the uniform-step loader (channel-block weight order, whole 32-channel "
-                     "blocks), the full split product and cout %% 128 == 0");
+                     "blocks), the full split product or VFML_CONV_MFMA2A (which then holds for the projection too) and "
+                     "cout %% 128 == 0");
         VFML_REQUIRE(d->proj_hi && d->proj_lo && d->proj_n > 0 && d->proj_n <= 48 && d->proj_n % 4 == 0 && d->proj_kp >= d->cout &&
                          d->proj_kp % 8 == 0 && d->ld_proj >= d->proj_n && d->ld_proj % 4 == 0 && vfml_aligned16(d->proj_out) &&
                          vfml_aligned16(d->proj_hi) && vfml_aligned16(d->proj_lo) && d->proj_scale > 0.f,

@@ -375,7 +375,8 @@ __device__ __forceinline__ void proj_weights_store(const u32x4 (&pw)[PROJ_PIECES
   });
 }
 
-template <int BN, int NT>
+// AHI (the "2a" product: activations as plain f16): the lo halves of relu(out) take no part - d = bh*ah + bl*ah.
+template <int BN, int NT, bool AHI>
 __device__ __forceinline__ void epilogue_proj_slab(const SplitArgs& a, float* sC, int m0, int n0, int t, int nrows, int rstride,
                                                    int roff) {
   static_assert(BN == 128 && NT == 256, "projection epilogue: 128-column tiles of four waves");
@@ -416,12 +417,13 @@ __device__ __forceinline__ void epilogue_proj_slab(const SplitArgs& a, float* sC
       bl[j] = *reinterpret_cast<const h16x8*>(brow + (PROJ_ROWS + 16 * j) * PROJ_ROW + ks * 64);
     }
     const h16x8 ah = *reinterpret_cast<const h16x8*>(arow + ks * 128);
-    const h16x8 al = *reinterpret_cast<const h16x8*>(arow + ks * 128 + 16);
+    h16x8 al;
+    if constexpr (!AHI) al = *reinterpret_cast<const h16x8*>(arow + ks * 128 + 16);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, d[j], 0, 0, 0);
       d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, d[j], 0, 0, 0);
-      d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, d[j], 0, 0, 0);
+      if constexpr (!AHI) d[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, d[j], 0, 0, 0);
     }
   });
   // lane: pixel row r of the wave's 16, projection columns 16 j + 4 g .. + 3

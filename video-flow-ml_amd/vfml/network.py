@@ -958,11 +958,13 @@ class MOFNetHIP(_Holder):
                     # flow head
                     wgt, b = P[f"{ub}.flow_head.conv1"]
                     wgt2, b2 = P[f"{ub}.flow_head.conv2"]
-                    if (self._tapsum and fuse_head and mf(f"{ub}.flow_head.conv1") == 3 and mf(f"{ub}.flow_head.conv2") == 3):
+                    nm_head = mf(f"{ub}.flow_head.conv1")
+                    if self._tapsum and fuse_head and nm_head in (3, "2a") and mf(f"{ub}.flow_head.conv2") == nm_head:
                         # both layers in ONE launch (vfml_conv_desc.proj_out): the 256-channel map stays in LDS, the launch
                         # leaves two partial 36-column maps (one per 128-channel half) that the tap sum adds
                         hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
-                                   epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=3, proj=wgt2, proj_out=fh_taps, ld_proj=36)
+                                   epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=nm_head, proj=wgt2, proj_out=fh_taps,
+                                   ld_proj=36)
                         hip.tapsum3x3(fh_taps, 36, b2, ng, h, w, delta, parts=2, part_stride=ng * Pn * 36)
                         hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
                                           flow_b_off=MF + 124, fmt_b=AF)
