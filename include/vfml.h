@@ -282,6 +282,10 @@ int vfml_flow_rows7(const float* flow, int n, int h, int w, float* rows, void* s
  * are added in order, map 0 first. */
 int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n, int h, int w, float* out, int parts, int64_t part_stride,
                    void* stream);
+/* The same sum used at once as an iteration's flow update: coords1[p] += it, then the flows are emitted as by
+ * vfml_coords_update(coords1, delta = that sum, ...) - one launch instead of two, same values. */
+int vfml_tapsum3x3_update(const float* t, int ld_t, const float* bias, int n, int h, int w, int parts, int64_t part_stride,
+                          float* coords1, float* flow_a, int ld_a, float* flow_b, int ld_b, int fmt_b, void* stream);
 
 /* coords1 += delta (4 floats per pixel: fwd x,y, bwd x,y); flow = coords1 - grid is written to
  * flow_a[p*ld_a..+4] and flow_b[p*ld_b..+4] (either may be NULL).  h,w give the pixel grid,

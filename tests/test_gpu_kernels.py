@@ -989,6 +989,36 @@ def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
         hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)
 
 
+@pytest.mark.parametrize("parts", [1, 2])
+def test_tapsum_update_is_tapsum_then_coords_update(gpu, parts):
+    """vfml_tapsum3x3_update == vfml_tapsum3x3 + vfml_coords_update, bit for bit (coords, the f32 flow and the flow quad of a
+    split-row unit)."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(5 + parts)
+    n, H, W, ld = 2, 11, 19, 36
+    P = n * H * W
+    taps = torch.randn(parts * P * ld, generator=g).cuda()
+    bias = torch.randn(4, generator=g).cuda()
+    res = []
+    for fused in (False, True):
+        coords = torch.empty(P * 4, device=gpu)
+        hip.coords_init(coords, n, H, W)
+        flow = torch.zeros(P * 4, device=gpu)
+        wide = torch.zeros(P * 16, device=gpu)
+        if fused:
+            hip.tapsum3x3_update(taps, ld, bias, n, H, W, coords, parts=parts, part_stride=P * ld, flow_a=flow, ld_a=4,
+                                 flow_b=wide, ld_b=16, flow_b_off=12, fmt_b=hip.FMT_S16)
+        else:
+            delta = torch.empty(P * 4, device=gpu)
+            hip.tapsum3x3(taps, ld, bias, n, H, W, delta, parts=parts, part_stride=P * ld)
+            hip.coords_update(coords, delta, n, H, W, flow_a=flow, ld_a=4, flow_b=wide, ld_b=16, flow_b_off=12,
+                              fmt_b=hip.FMT_S16)
+        res.append((coords, flow, wide))
+    for a, b in zip(*res):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert res[0][1].abs().max() > 0
+
+
 @pytest.mark.parametrize("n,H,W,tile", [(3, 135, 240, None), (1, 17, 23, "3,2,2,2"), (2, 9, 14, "2,2,2,2")])
 def test_projection_epilogue_is_the_two_layer_flow_head(gpu, monkeypatch, n, H, W, tile):
     """vfml_conv_desc.proj_out: conv 3x3 (128 -> 256) + ReLU + 1x1 (256 -> 36) in one launch - the partial maps of the two

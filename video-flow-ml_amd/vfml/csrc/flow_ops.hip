@@ -319,9 +319,40 @@ __global__ void flow_rows7_kernel(const f32x4* __restrict__ flow, int w, int64_t
   }
 }
 
-// out[p] = bias + sum of the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3)
+// coords[p] (already updated) -> flow = coords - grid, written to fa[p*lda..+4] (f32) and fb[p*ldb..+4] (f32, or the second quad
+// of a split-row unit)
+__device__ __forceinline__ void emit_flow(int64_t p, const f32x4 c, int h, int w, float* __restrict__ fa, int lda,
+                                          float* __restrict__ fb, int ldb, int b16) {
+  const float x = (float)(int)(p % w);
+  const float y = (float)(int)((p / w) % h);
+  const f32x4 f = {c[0] - x, c[1] - y, c[2] - x, c[3] - y};
+  if (fa) *reinterpret_cast<f32x4*>(fa + p * lda) = f;
+  if (fb) {
+    if (b16) {   // second quad of a split-row unit: hi halves at +0 (8 B), lo halves 16 B further
+      typedef vfml_h16x2 fp16x2_;
+      fp16x2_ h0, h1, l0, l1;
+      vfml_split2(f[0], f[1], h0, l0);
+      vfml_split2(f[2], f[3], h1, l1);
+      // fb points at channel 4 of the unit = byte 16 of it in f32 addressing; the quad slot of the
+      // hi halves is byte 8 of the unit
+      char* u = reinterpret_cast<char*>(fb + p * ldb) - 16;
+      *reinterpret_cast<fp16x2_*>(u + 8) = h0;
+      *reinterpret_cast<fp16x2_*>(u + 12) = h1;
+      *reinterpret_cast<fp16x2_*>(u + 24) = l0;
+      *reinterpret_cast<fp16x2_*>(u + 28) = l1;
+    } else {
+      *reinterpret_cast<f32x4*>(fb + p * ldb) = f;
+    }
+  }
+}
+
+// out[p] = bias + sum of the nine taps' quads of the tap-major 36-column map t (include/vfml.h vfml_tapsum3x3); with `coords`
+// the sum is the flow update of the iteration: coords[p] += it and the flows are emitted as vfml_coords_update does
+// (vfml_tapsum3x3_update: one launch instead of two)
 __global__ void tapsum3x3_kernel(const float* __restrict__ t, int ld, const float* __restrict__ bias, int h, int w,
-                                 int64_t total, f32x4* __restrict__ out, int parts, int64_t part_stride) {
+                                 int64_t total, f32x4* __restrict__ out, int parts, int64_t part_stride,
+                                 f32x4* __restrict__ coords, float* __restrict__ fa, int lda, float* __restrict__ fb, int ldb,
+                                 int b16) {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
     const int x = (int)(p % w), y = (int)((p / w) % h);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -338,7 +369,12 @@ __global__ void tapsum3x3_kernel(const float* __restrict__ t, int ld, const floa
           s = s + v;
         }
       }
-    out[p] = s;
+    if (out) out[p] = s;
+    if (coords) {
+      const f32x4 c = coords[p] + s;
+      coords[p] = c;
+      emit_flow(p, c, h, w, fa, lda, fb, ldb, b16);
+    }
   }
 }
 
@@ -351,27 +387,7 @@ __global__ void coords_update_kernel(f32x4* __restrict__ coords, const f32x4* __
       c = c + delta[p];
       coords[p] = c;
     }
-    const float x = (float)(int)(p % w);
-    const float y = (float)(int)((p / w) % h);
-    const f32x4 f = {c[0] - x, c[1] - y, c[2] - x, c[3] - y};
-    if (fa) *reinterpret_cast<f32x4*>(fa + p * lda) = f;
-    if (fb) {
-      if (b16) {   // second quad of a split-row unit: hi halves at +0 (8 B), lo halves 16 B further
-        typedef vfml_h16x2 fp16x2_;
-        fp16x2_ h0, h1, l0, l1;
-        vfml_split2(f[0], f[1], h0, l0);
-        vfml_split2(f[2], f[3], h1, l1);
-        // fb points at channel 4 of the unit = byte 16 of it in f32 addressing; the quad slot of the
-        // hi halves is byte 8 of the unit
-        char* u = reinterpret_cast<char*>(fb + p * ldb) - 16;
-        *reinterpret_cast<fp16x2_*>(u + 8) = h0;
-        *reinterpret_cast<fp16x2_*>(u + 12) = h1;
-        *reinterpret_cast<fp16x2_*>(u + 24) = l0;
-        *reinterpret_cast<fp16x2_*>(u + 28) = l1;
-      } else {
-        *reinterpret_cast<f32x4*>(fb + p * ldb) = f;
-      }
-    }
+    emit_flow(p, c, h, w, fa, lda, fb, ldb, b16);
   }
 }
 
@@ -678,8 +694,30 @@ extern "C" int vfml_tapsum3x3(const float* t, int ld_t, const float* bias, int n
                "vfml_tapsum3x3: ld_t must be a multiple of 4 and >= 36, t and out 16-byte aligned");
   const int64_t total = (int64_t)n * h * w;
   hipLaunchKernelGGL(tapsum3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
-                     ld_t, bias, h, w, total, (f32x4*)out, parts, part_stride);
+                     ld_t, bias, h, w, total, (f32x4*)out, parts, part_stride, (f32x4*)nullptr, (float*)nullptr, 0, (float*)nullptr,
+                     0, 0);
   return vfml_check_launch("vfml_tapsum3x3");
+}
+
+extern "C" int vfml_tapsum3x3_update(const float* t, int ld_t, const float* bias, int n, int h, int w, int parts,
+                                     int64_t part_stride, float* coords1, float* flow_a, int ld_a, float* flow_b, int ld_b,
+                                     int fmt_b, void* stream) {
+  VFML_REQUIRE(t && coords1 && n > 0 && h > 0 && w > 0, "vfml_tapsum3x3_update: bad argument");
+  VFML_REQUIRE(parts >= 1 && parts <= 4 && (parts == 1 || (part_stride > 0 && part_stride % 4 == 0)),
+               "vfml_tapsum3x3_update: parts in 1..4, part_stride a positive multiple of 4 floats");
+  VFML_REQUIRE(ld_t >= 36 && ld_t % 4 == 0 && vfml_aligned16(t), "vfml_tapsum3x3_update: ld_t must be a multiple of 4 and >= 36, t 16-byte aligned");
+  VFML_REQUIRE(fmt_b == VFML_FMT_F32 || fmt_b == VFML_FMT_S16, "vfml_tapsum3x3_update: bad fmt_b");
+  if (fmt_b == VFML_FMT_S16 && flow_b)
+    VFML_REQUIRE((reinterpret_cast<uintptr_t>(flow_b) & 31u) == 16 && ld_b % 8 == 0,
+                 "vfml_tapsum3x3_update: split-row flow_b must point at channel 4 of a unit (ld_b %% 8 == 0)");
+  VFML_REQUIRE(vfml_aligned16(coords1) && vfml_aligned16(flow_a) && vfml_aligned16(flow_b), "vfml_tapsum3x3_update: alignment");
+  VFML_REQUIRE((!flow_a || (ld_a >= 4 && ld_a % 4 == 0)) && (!flow_b || (ld_b >= 4 && ld_b % 4 == 0)),
+               "vfml_tapsum3x3_update: ld must be a multiple of 4 and >= 4");
+  const int64_t total = (int64_t)n * h * w;
+  hipLaunchKernelGGL(tapsum3x3_kernel, dim3(grid_for(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t,
+                     ld_t, bias, h, w, total, (f32x4*)nullptr, parts, part_stride, (f32x4*)coords1, flow_a, ld_a, flow_b, ld_b,
+                     fmt_b == VFML_FMT_S16 ? 1 : 0);
+  return vfml_check_launch("vfml_tapsum3x3_update");
 }
 
 extern "C" int vfml_flow_lod(const float* flow, int h, int w, float* out, void* stream) {

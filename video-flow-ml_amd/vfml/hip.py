@@ -143,6 +143,8 @@ def lib():
                                             c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                             c_void_p]
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
+    L.vfml_tapsum3x3_update.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p,
+                                        c_int, c_void_p, c_int, c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_flow_rows7.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]
@@ -167,7 +169,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
-    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_flow_rows7",
+    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_tapsum3x3_update", "vfml_flow_rows7",
     "vfml_convex_upsample", "vfml_stem7x7s2", "vfml_stem7x7s2_chunks", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -626,6 +628,14 @@ def tapsum3x3(t, ld_t, bias, n, h, w, out, parts=1, part_stride=0):
     that many maps part_stride floats apart whose sum is meant (conv2d(..., proj_out=))."""
     _check(lib().vfml_tapsum3x3(_ptr(_dev(t)), ld_t, _ptr(bias) if bias is not None else None, n, h, w, _ptr(_dev(out)),
                                 parts, part_stride, _stream()), "vfml_tapsum3x3")
+
+
+def tapsum3x3_update(t, ld_t, bias, n, h, w, coords1, parts=1, part_stride=0, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None,
+                     ld_b=0, flow_b_off=0, fmt_b=FMT_F32):
+    """tapsum3x3 and coords_update(delta = that sum) as one launch (include/vfml.h vfml_tapsum3x3_update)."""
+    _check(lib().vfml_tapsum3x3_update(_ptr(_dev(t)), ld_t, _ptr(bias) if bias is not None else None, n, h, w, parts, part_stride,
+                                       _ptr(_dev(coords1)), _ptr(flow_a, flow_a_off), ld_a, _ptr(flow_b, flow_b_off), ld_b,
+                                       fmt_b, _stream()), "vfml_tapsum3x3_update")
 
 
 def coords_update(coords1, delta, n, h, w, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None, ld_b=0, flow_b_off=0,

@@ -965,9 +965,8 @@ class MOFNetHIP(_Holder):
                         hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                                    epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=nm_head, proj=wgt2, proj_out=fh_taps,
                                    ld_proj=36)
-                        hip.tapsum3x3(fh_taps, 36, b2, ng, h, w, delta, parts=2, part_stride=ng * Pn * 36)
-                        hip.coords_update(coords1, delta, ng, h, w, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
-                                          flow_b_off=MF + 124, fmt_b=AF)
+                        hip.tapsum3x3_update(fh_taps, 36, b2, ng, h, w, coords1, parts=2, part_stride=ng * Pn * 36, flow_a=flow4,
+                                             ld_a=4, flow_b=G, ld_b=GLD, flow_b_off=MF + 124, fmt_b=AF)
                         continue
                     hip.conv2d(G, 128, GLD, ng, h, w, wgt, b, 256, 3, 3, fh, 256, in0_off=HH, pad_h=1, pad_w=1,
                                epilogue=hip.EPI_RELU, in_fmt=AF, out_fmt=AF, mfma=mf(f"{ub}.flow_head.conv1"))
@@ -976,7 +975,9 @@ class MOFNetHIP(_Holder):
                         # 256 -> 4 over 3x3 as a 1x1 to 36 tap-major columns + the nine taps summed per pixel (_pack)
                         hip.conv2d(fh, 256, 256, ng, h, w, wgt, None, 36, 1, 1, fh_taps, 36, in_fmt=AF,
                                    mfma=mf(f"{ub}.flow_head.conv2"))
-                        hip.tapsum3x3(fh_taps, 36, b, ng, h, w, delta)
+                        hip.tapsum3x3_update(fh_taps, 36, b, ng, h, w, coords1, flow_a=flow4, ld_a=4, flow_b=G, ld_b=GLD,
+                                             flow_b_off=MF + 124, fmt_b=AF)
+                        continue
                     else:
                         hip.conv2d(fh, 256, 256, ng, h, w, wgt, b, 4, 3, 3, delta, 4, pad_h=1, pad_w=1, in_fmt=AF,
                                    mfma=mf(f"{ub}.flow_head.conv2"))
