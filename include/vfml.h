@@ -264,6 +264,15 @@ int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* 
 int vfml_corr_lookup_indirect(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                               int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
                               float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream);
+/* Both directions of a window's centre frames in ONE launch: `table` holds the forward problems' pyramids of the query maps
+ * from entry 0 and their backward problems' from entry dir_tab * levels (dir_tab >= nmaps; 2 * nmaps <= 8 maps per launch).
+ * The second direction of query map m reads the coordinates at coords[row * ld_coords + dir_coords ..] and writes to
+ * out[row * ld_out + dir_out ..] - what two calls of vfml_corr_lookup_indirect with shifted table / coords / out pointers
+ * do, bit for bit. */
+int vfml_corr_lookup_indirect_bidir(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
+                                    int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
+                                    int dir_coords, float* out, int ld_out, int dir_out, int dir_tab, int out_fmt, int vol_fmt,
+                                    int vol_tile, void* stream);
 int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream);
 
 /* The 7x7 convolution over the 4-channel flow map (motion encoder, convf1) as a 7x1 convolution over 32 channels: this pass

@@ -989,6 +989,50 @@ def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
         hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)
 
 
+def test_bidirectional_lookup_is_two_lookups(gpu):
+    """vfml_corr_lookup_indirect_bidir == the forward and the backward lookup as two launches, bit for bit (fewer query maps
+    than the table holds per direction, split-row output, tiled volumes with an f16 level)."""
+    from vfml import hip
+    g = torch.Generator().manual_seed(21)
+    h, w, R, M, nm = 12, 20, 4, 3, 2
+    Pn = h * w
+    tile = hip.VolTile(3, 2)
+    hl = [h >> l for l in range(4)]
+    wl = [w >> l for l in range(4)]
+    ldl = [((tile.count(hl[l], wl[l]) + 31) // 32) * 32 + 32 for l in range(4)]
+    rows = tile.count(h, w)
+    pyr = {}
+    for d in ("f", "b"):
+        pyr[d] = []
+        for m in range(M):
+            lv = []
+            for l in range(4):
+                t = torch.randn(rows * ldl[l], generator=g)
+                lv.append(t.half().cuda().view(torch.float32) if l == 3 else t.cuda())
+            pyr[d].append(lv)
+    tabs = {k: torch.zeros(64, dtype=torch.int64, device=gpu) for k in ("f", "b", "fb")}
+    hip.ptr_table_set(tabs["f"], [p for m in pyr["f"] for p in m])
+    hip.ptr_table_set(tabs["b"], [p for m in pyr["b"] for p in m])
+    hip.ptr_table_set(tabs["fb"], [p for d in ("f", "b") for m in pyr[d] for p in m])
+    coords = (torch.rand(M * Pn, 4, generator=g) * torch.tensor([w, h, w, h]) * 1.2 - 2.0).reshape(-1).cuda()
+    cor_p = 336
+    VF = hip.vol_f16_levels(8)
+    outs = []
+    for fused in (False, True):
+        out = torch.zeros(M * Pn * 2 * cor_p, device=gpu)
+        if fused:
+            hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords, 0, 4, out, 0, 2 * cor_p, out_fmt=hip.FMT_S16, table=tabs["fb"],
+                            nmaps=nm, vol_fmt=VF, vol_tile=tile.code, bidir=(2, cor_p, M))
+        else:
+            hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords, 0, 4, out, 0, 2 * cor_p, out_fmt=hip.FMT_S16, table=tabs["f"],
+                            nmaps=nm, vol_fmt=VF, vol_tile=tile.code)
+            hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords, 2, 4, out, cor_p, 2 * cor_p, out_fmt=hip.FMT_S16, table=tabs["b"],
+                            nmaps=nm, vol_fmt=VF, vol_tile=tile.code)
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert outs[0][:nm * Pn * 2 * cor_p].abs().max() > 0 and (outs[0][nm * Pn * 2 * cor_p:] == 0).all()
+
+
 @pytest.mark.parametrize("parts", [1, 2])
 def test_tapsum_update_is_tapsum_then_coords_update(gpu, parts):
     """vfml_tapsum3x3_update == vfml_tapsum3x3 + vfml_coords_update, bit for bit (coords, the f32 flow and the flow quad of a

@@ -30,7 +30,20 @@ struct LookupArgs {
   int vol16;     // bit l: level l of the pyramids holds one f16 per element (VFML_FMT_F16 / VFML_VOL_F16_LEVELS; fixed-radius kernels only)
   int tws, ths;  // vol_tile: a level image (and the query grid that orders the rows) stored in (1<<tws) x (1<<ths) tiles; 0, 0: row-major
   int qw;        // width of the query grid (= wl[0]) when tiled: query q reads volume row tiled_at(q / qw, q % qw)
+  // two directions in one launch (vfml_corr_lookup_indirect_bidir): maps dir_maps .. 2 dir_maps - 1 are the second direction
+  // of the same queries - their coordinates dir_coords floats, their output dir_out floats behind the first direction's
+  int dir_maps, dir_coords, dir_out;
+  int dir_tab;   // table index (in maps) of the second direction's first pyramid
 };
+
+// query q of a launch -> the row of coords / out it belongs to and the float offsets of its direction
+__device__ __forceinline__ void lookup_rows(const LookupArgs& a, int q, int& map, int64_t& crow, int64_t& orow) {
+  const int dir = a.dir_maps && map >= a.dir_maps;
+  const int64_t qd = q - (dir ? a.dir_maps * a.q_per_map : 0);
+  if (dir) map += a.dir_tab - a.dir_maps;        // (from here on `map` names the pyramid: its place in the table)
+  crow = qd * a.ld_coords + (dir ? a.dir_coords : 0);
+  orow = qd * a.ld_out + (dir ? a.dir_out : 0);
+}
 
 // Position of texel (y, x) of a w-wide image stored as (1<<tws) x (1<<ths) tiles, tile after tile, each tile row-major
 // (tws = ths = 0: plain row-major).  A (2r+2)^2 lookup window then lies in ~8 128-byte lines instead of ~13 (ten 40-byte row
@@ -65,14 +78,16 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
   const int wv = threadIdx.x >> 6;
   const int q = blockIdx.x * LOOKUP_WAVES + wv;
   const bool live = q < a.nq;
-  const int map = live ? q / a.q_per_map : 0;
+  int map = live ? q / a.q_per_map : 0;
   const int qq = q - map * a.q_per_map;      // row inside that map's pyramid
   const int side = 2 * a.radius + 2;  // patch side
   const int win = 2 * a.radius + 1;
   const int psz = side * side;
+  int64_t crow = 0, orow = 0;
+  if (live) lookup_rows(a, q, map, crow, orow);
   if (live) {
-    const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
-    const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
+    const float cx = a.coords[crow + 0];
+    const float cy = a.coords[crow + 1];
     const int total = a.levels * psz;
     const int qrow = (a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq;
     for (int e = lane; e < total; e += 64) {
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_kernel(const Lo
   __syncthreads();
   if (!live) return;
   const int nout = a.levels * win * win;
-  float* o = a.out + (int64_t)q * a.ld_out;
+  float* o = a.out + orow;
   const int nwrite = a.out16 ? (nout + 7) & ~7 : nout;   // split rows: zero-fill up to a whole unit
   for (int c = lane; c < nwrite; c += 64) {
     if (c >= nout) {
@@ -168,11 +183,13 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
   const int q = blockIdx.x * LOOKUP_WAVES + wv;       // the wave's query: everything derived from it is scalar
   if (q >= a.nq) return;
   // (integer division runs on the vector unit: readfirstlane tells the compiler its result is still one value per wave)
-  const int map = __builtin_amdgcn_readfirstlane(q / a.q_per_map);
+  int map = __builtin_amdgcn_readfirstlane(q / a.q_per_map);
   const int qq = q - map * a.q_per_map;
   const int qrow = __builtin_amdgcn_readfirstlane((a.tws | a.ths) ? tiled_at(qq / a.qw, qq % a.qw, a.qw, a.tws, a.ths) : qq);
-  const float cx = a.coords[(int64_t)q * a.ld_coords + 0];
-  const float cy = a.coords[(int64_t)q * a.ld_coords + 1];
+  int64_t crow, orow;
+  lookup_rows(a, q, map, crow, orow);
+  const float cx = a.coords[crow + 0];
+  const float cy = a.coords[crow + 1];
   // the two passes of a level: window cells lane and lane + 64 (the second pass: cells 64 .. PSZ-1)
   const int pyA = lane / SIDE, pxA = lane - pyA * SIDE;
   const int pyB = (lane + 64) / SIDE, pxB = (lane + 64) - pyB * SIDE;
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(64 * LOOKUP_WAVES) void corr_lookup_fixed_kernel(co
   }
   wave_lds_sync();
   if (lane < nunits) {
-    float* o = a.out + (int64_t)q * a.ld_out + lane * 8;
+    float* o = a.out + orow + lane * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(&outs[wv][lane * 8]);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(&outs[wv][lane * 8 + 4]);
     if (OUT16) {
@@ -478,7 +495,8 @@ extern "C" int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, v
 
 static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
                             const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream);
+                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream,
+                            int dir_maps = 0, int dir_coords = 0, int dir_out = 0, int dir_tab = 0);
 
 extern "C" int vfml_corr_lookup(const float* const* pyr, const int32_t* hl, const int32_t* wl, const int32_t* ld,
                                 int levels, int radius, int nmaps, int q_per_map, const float* coords, int ld_coords,
@@ -496,9 +514,24 @@ extern "C" int vfml_corr_lookup_indirect(const float* const* table, const int32_
                           out_fmt, vol_fmt, vol_tile, stream);
 }
 
+extern "C" int vfml_corr_lookup_indirect_bidir(const float* const* table, const int32_t* hl, const int32_t* wl, const int32_t* ld,
+                                               int levels, int radius, int nmaps, int q_per_map, const float* coords,
+                                               int ld_coords, int dir_coords, float* out, int ld_out, int dir_out, int dir_tab,
+                                               int out_fmt, int vol_fmt, int vol_tile, void* stream) {
+  VFML_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7u) == 0, "vfml_corr_lookup_indirect_bidir: null / misaligned table");
+  VFML_REQUIRE(nmaps >= 1 && 2 * nmaps <= MAX_MAPS, "vfml_corr_lookup_indirect_bidir: nmaps=%d out of [1,%d]", nmaps, MAX_MAPS / 2);
+  VFML_REQUIRE(dir_coords >= 0 && dir_coords + 2 <= ld_coords && dir_out >= 0 && dir_out % 8 == 0,
+               "vfml_corr_lookup_indirect_bidir: dir_coords within a coords row, dir_out a multiple of 8 floats");
+  VFML_REQUIRE(dir_tab >= nmaps && (dir_tab + nmaps) * levels <= MAX_TABLE,
+               "vfml_corr_lookup_indirect_bidir: dir_tab=%d (the second direction's first map in the table) out of range", dir_tab);
+  return corr_lookup_impl(nullptr, table, hl, wl, ld, levels, radius, 2 * nmaps, q_per_map, coords, ld_coords, out, ld_out,
+                          out_fmt, vol_fmt, vol_tile, stream, nmaps, dir_coords, dir_out, dir_tab);
+}
+
 static int corr_lookup_impl(const float* const* pyr, const float* const* table, const int32_t* hl, const int32_t* wl,
                             const int32_t* ld, int levels, int radius, int nmaps, int q_per_map, const float* coords,
-                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream) {
+                            int ld_coords, float* out, int ld_out, int out_fmt, int vol_fmt, int vol_tile, void* stream,
+                            int dir_maps, int dir_coords, int dir_out, int dir_tab) {
   VFML_REQUIRE(nmaps >= 1 && nmaps <= MAX_MAPS && q_per_map > 0, "vfml_corr_lookup: nmaps=%d out of [1,%d] or empty maps", nmaps, MAX_MAPS);
   const int nq = nmaps * q_per_map;
   VFML_REQUIRE(out_fmt == VFML_FMT_F32 || out_fmt == VFML_FMT_S16, "vfml_corr_lookup: bad out_fmt");
@@ -547,6 +580,7 @@ static int corr_lookup_impl(const float* const* pyr, const float* const* table, 
   }
   a.levels = levels; a.radius = radius; a.nq = nq; a.q_per_map = q_per_map;
   a.coords = coords; a.ld_coords = ld_coords; a.out = out; a.ld_out = ld_out;
+  a.dir_maps = dir_maps; a.dir_coords = dir_coords; a.dir_out = dir_out; a.dir_tab = dir_tab;
   const dim3 grid((nq + LOOKUP_WAVES - 1) / LOOKUP_WAVES), block(64 * LOOKUP_WAVES);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int generic = getenv("VFML_LOOKUP_GENERIC") ? atoi(getenv("VFML_LOOKUP_GENERIC")) : 0;

@@ -142,6 +142,9 @@ def lib():
     L.vfml_corr_lookup_indirect.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                             c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                             c_void_p]
+    L.vfml_corr_lookup_indirect_bidir.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                                  c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                                  c_int, c_int, c_int, c_int, c_void_p]
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_tapsum3x3_update.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p,
                                         c_int, c_void_p, c_int, c_int, c_void_p]
@@ -168,7 +171,7 @@ def lib():
 EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
-    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect",
+    "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect", "vfml_corr_lookup_indirect_bidir",
     "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_tapsum3x3_update", "vfml_flow_rows7",
     "vfml_convex_upsample", "vfml_stem7x7s2", "vfml_stem7x7s2_chunks", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
@@ -544,14 +547,25 @@ def ptr_table_set(table, tensors):
 
 
 def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coords, out, out_off, ld_out,
-                out_fmt=FMT_F32, table=None, nmaps=None, vol_fmt=FMT_F32, vol_tile=0):
+                out_fmt=FMT_F32, table=None, nmaps=None, vol_fmt=FMT_F32, vol_tile=0, bidir=None):
     """pyrs: list (one entry per query map) of lists (one flat float32 device tensor per level, rows =
     that map's q_per_map queries).  Queries / coords / out rows are ordered map-major.
     table (with nmaps): instead of `pyrs`, an int64 device tensor holding the same pointers, map-major
     (ptr_table_set), read when the kernel runs (vfml_corr_lookup_indirect).
-    vol_tile: 0 (row-major level images, rows in query order) or VolTile.code (include/vfml.h)."""
+    vol_tile: 0 (row-major level images, rows in query order) or VolTile.code (include/vfml.h).
+    bidir = (dir_coords, dir_out, dir_tab) with a table: both directions of the nmaps query maps in one launch
+    (vfml_corr_lookup_indirect_bidir)."""
     L = len(hl)
-    if table is not None:
+    if bidir is not None:
+        dir_coords, dir_out, dir_tab = bidir
+
+        def launch():
+            _check(lib().vfml_corr_lookup_indirect_bidir(c_void_p(table.data_ptr()), (c_int32 * L)(*hl), (c_int32 * L)(*wl),
+                                                         (c_int32 * L)(*ld), L, radius, nmaps, q_per_map,
+                                                         _ptr(_dev(coords), coords_off), ld_coords, dir_coords,
+                                                         _ptr(_dev(out), out_off), ld_out, dir_out, dir_tab, out_fmt, vol_fmt,
+                                                         vol_tile, _stream()), "vfml_corr_lookup_indirect_bidir")
+    elif table is not None:
         def launch():
             _check(lib().vfml_corr_lookup_indirect(c_void_p(table.data_ptr()), (c_int32 * L)(*hl), (c_int32 * L)(*wl),
                                                    (c_int32 * L)(*ld), L, radius, nmaps, q_per_map,
@@ -575,7 +589,7 @@ def corr_lookup(pyrs, hl, wl, ld, radius, q_per_map, coords, coords_off, ld_coor
     launch()
     e1.record()
     # algorithmic bytes: per query and level the (2r+2)^2 integer-grid patch in, (2r+1)^2 samples out
-    q = nmaps * q_per_map
+    q = (2 if bidir is not None else 1) * nmaps * q_per_map
     m16 = _vol_mask(vol_fmt, L)
     texel_bytes = sum(2.0 if (m16 >> l) & 1 else 4.0 for l in range(L))
     _PROFILE_HBM.append(("corr_lookup", q * ((2 * radius + 2) ** 2 * texel_bytes + L * (2 * radius + 1) ** 2 * 4.0), e0, e1))

@@ -858,6 +858,12 @@ class MOFNetHIP(_Holder):
             tab_b = self._buf("pyr_table_b", 64, dev, torch.int64)
             hip.ptr_table_set(tab_f, [p for m in pyrs["f"] for p in m])
             hip.ptr_table_set(tab_b, [p for m in pyrs["b"] for p in m])
+            # both directions behind one another in one table: the two lookups of an iteration as ONE launch (at most 8 maps;
+            # A/B switch VFML_LOOKUP_BIDIR=0)
+            bidir = 2 * M <= 8 and 2 * M * L <= 48 and os.environ.get("VFML_LOOKUP_BIDIR", "1") != "0"
+            if bidir:
+                tab_fb = self._buf("pyr_table_fb", 64, dev, torch.int64)
+                hip.ptr_table_set(tab_fb, [p for d in ("f", "b") for m in pyrs[d] for p in m])
             no = 1 if pick_only and not self.tri_frame else M
             nflows = 1 if pick_only and not self.tri_frame else 2 * M
             up_fixed = self._buf("up_out", nflows * H * W * 2, dev)
@@ -911,10 +917,14 @@ class MOFNetHIP(_Holder):
                             join = torch.cuda.Event()
                             join.record()
                     # K5
-                    hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF,
-                                    table=tab_f, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
-                    hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF,
-                                    table=tab_b, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
+                    if bidir:
+                        hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF, table=tab_fb,
+                                        nmaps=nm, vol_fmt=VF, vol_tile=TILE, bidir=(2, cor_p, M))
+                    else:
+                        hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 0, 4, corr, 0, 2 * cor_p, out_fmt=AF,
+                                        table=tab_f, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
+                        hip.corr_lookup(None, hl, wl, ldl, R, Pn, coords1, 2, 4, corr, cor_p, 2 * cor_p, out_fmt=AF,
+                                        table=tab_b, nmaps=nm, vol_fmt=VF, vol_tile=TILE)
                     # motion encoder
                     wgt, b = P[f"{ub}.encoder.convc1"]
                     hip.conv2d(corr, 2 * cor_p, 2 * cor_p, nm, h, w, wgt, b, 256, 1, 1, c1, 256, epilogue=hip.EPI_RELU,
@@ -1001,7 +1011,7 @@ class MOFNetHIP(_Holder):
                                                 up_fixed, out_off=(d * M + c) * H * W * 2)
 
             gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(), vol16,
-                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"), os.environ.get("VFML_FUSE_HEAD", "1"))
+                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"), os.environ.get("VFML_FUSE_HEAD", "1"), bidir)
             self._pre_body = torch.cuda.Event()
             self._pre_body.record(torch.cuda.current_stream(dev))      # (what a prefetch of the next window waits for)
             self._run_body(body, gkey, dev)
