@@ -109,6 +109,11 @@ typedef struct vfml_conv_desc {
      FlowHead. */
   const void* proj_hi; const void* proj_lo; int32_t proj_n; int32_t proj_kp; float proj_scale;
   float* proj_out; int32_t ld_proj;
+  /* optional (vfml_conv2d_split): a DEVICE cell (8-byte aligned) holding the addend pointer to use, read when the kernel
+     runs - the launch can sit in a replayed HIP graph while the per-pixel bias it adds (the context part of a GRU gate
+     convolution, kept per frame) lives somewhere else from field to field.  `addend` must still be given: a pointer of the
+     same shape and alignment, which is what the call validates (vfml_ptr_table_set writes such cells). */
+  const float* const* addend_ind;
 } vfml_conv_desc;
 
 /* flags: accumulate the two cross terms of the split product in the order (a_lo*b_hi, a_hi*b_lo) instead of

@@ -50,10 +50,10 @@ def test_conv_desc_layout_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        m = re.match(r"(const float\*|const void\*|float\*|double\*|int32_t|float)\s+(.*)", decl)
+        m = re.match(r"(const float\* const\*|const float\*|const void\*|float\*|double\*|int32_t|float)\s+(.*)", decl)
         for name in m.group(2).split(","):
             fields.append((name.strip(), m.group(1)))
-    want = {"const float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "double*": ctypes.c_void_p, "int32_t": ctypes.c_int32,
+    want = {"const float* const*": ctypes.c_void_p, "const float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "float*": ctypes.c_void_p, "double*": ctypes.c_void_p, "int32_t": ctypes.c_int32,
             "float": ctypes.c_float}
     assert [(n, want[t]) for n, t in fields] == list(hip.ConvDesc._fields_)
 

@@ -109,6 +109,44 @@ def test_sliding_window_feature_cache_is_exact(gpu):
     assert torch.equal(t1, t2[0, 3].permute(1, 2, 0))
 
 
+def test_context_store_ring_wraps_and_falls_back(gpu, monkeypatch):
+    """The gate convolutions' per-frame context parts live in a ring of frame slots that the launches reach through a device
+    cell (vfml_conv_desc.addend_ind): a sliding job longer than the ring (it wraps through the mirrored first slots), the same
+    frames in random order (centres not in arrival order: gathered) and VFML_CTX_GATHER=1 (every window gathered) all give
+    the bits of windows computed from scratch."""
+    import contextlib
+    import io
+    import numpy as np
+    from processing.videoflow_processor import VideoFlowProcessor
+    from vfml.synth import synthetic_clip
+    net, _ = _pair()
+    nfr = 2 * net.CTX_RING + 3
+    frames = synthetic_clip(nfr, 128, 160)
+    clip = torch.from_numpy(np.stack(frames)).cuda()
+    with contextlib.redirect_stdout(io.StringIO()):
+        proc = VideoFlowProcessor("cuda", sequence_length=5)
+    proc.core.model = net
+    ref = []
+    for i in range(nfr):                                   # from scratch (no keys: nothing cached)
+        b, _ = net.forward_u8(clip[proc.window_indices(nfr, i)])
+        ref.append(b[0, 3].permute(1, 2, 0).clone())
+    net.clear_feature_cache()
+    wrapped = 0
+    for i in range(nfr):                                   # the sliding job
+        a = proc.compute_optical_flow_resident(clip, i)
+        assert torch.equal(a, ref[i]), i
+        live = sorted(net._ctx_store["live"])
+        wrapped += live != list(range(live[0], live[0] + len(live)))
+    assert wrapped >= 2                                    # (windows whose centres straddle the end of the ring)
+    order = np.random.default_rng(0).permutation(nfr)
+    for i in order[:12]:                                   # random access over the same (partly cached) frames
+        assert torch.equal(proc.compute_optical_flow_resident(clip, int(i)), ref[int(i)]), int(i)
+    monkeypatch.setenv("VFML_CTX_GATHER", "1")
+    net.clear_feature_cache()
+    for i in range(6):
+        assert torch.equal(proc.compute_optical_flow_resident(clip, i), ref[i]), i
+
+
 def test_engine_refuses_cpu_tensors():
     from vfml import build_network, get_cfg
     net = build_network(get_cfg())

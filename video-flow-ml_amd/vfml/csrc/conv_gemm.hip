@@ -267,6 +267,7 @@ extern "C" int vfml_conv2d(const vfml_conv_desc* d, void* stream) {
   a.in0 = d->in0; a.in1 = two ? d->in1 : d->in0;
   a.weight = d->weight; a.bias = d->bias; a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
   a.addend = d->addend; a.ld_addend = d->ld_addend;
+  VFML_REQUIRE(!d->addend_ind, "vfml_conv2d: addend_ind is implemented by vfml_conv2d_split only");
   VFML_REQUIRE(!d->addend || d->ld_addend >= d->cout, "vfml_conv2d: ld_addend=%d < cout", d->ld_addend);
   a.c0 = d->c0; a.ld0 = d->ld0; a.c1 = d->c1; a.ld1 = two ? d->ld1 : d->ld0; a.ctot = d->c0 + d->c1;
   a.H = d->h; a.W = d->w; a.ho = ho; a.wo = wo;

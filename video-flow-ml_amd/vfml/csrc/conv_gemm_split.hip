@@ -1524,6 +1524,9 @@ extern "C" int vfml_conv2d_split(const vfml_conv_desc* d, const void* w_hi, cons
   a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo; a.bias = d->bias;
   a.aux0 = d->aux0; a.aux1 = d->aux1; a.out = d->out;
   a.addend = d->addend; a.ld_addend = d->ld_addend;
+  a.addend_ind = d->addend_ind;
+  VFML_REQUIRE(!d->addend_ind || (d->addend && (reinterpret_cast<uintptr_t>(d->addend_ind) & 7u) == 0),
+               "vfml_conv2d_split: addend_ind goes with an addend of the same shape and alignment (what the call validates) and is 8-byte aligned");
   a.c0 = d->c0; a.ld0 = d->ld0; a.c1 = d->c1; a.ld1 = two ? d->ld1 : d->ld0; a.ctot = d->c0 + d->c1;
   a.H = d->h; a.W = d->w; a.ho = ho; a.wo = wo;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;

@@ -46,6 +46,7 @@ struct SplitArgs {
   // projection epilogue (vfml_conv_desc.proj_*): relu(out) is not stored but multiplied, per 128-column tile, by that
   // tile's slice of a second [proj_n][cout] weight (two f16 planes, lo plane proj_lo_off bytes behind the hi plane)
   const char* proj_w; int proj_lo_off, proj_bytes, proj_n, proj_kp; float proj_inv; float* proj_out; int ld_proj;
+  const float* const* addend_ind;   // vfml_conv_desc.addend_ind: a device cell holding the addend pointer to use (or null)
 };
 // conv_gemm_tapx.hip: the kernel that shares one activation stage between the taps of a filter row
 #define VFML_TAPX_KWMAX 5      // widest filter row it is built for
@@ -86,6 +87,15 @@ __device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, int voff_b
 constexpr int OOB = 0x7fffffff;   // >= any num_records we create (all < 2^31 bytes)
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// the addend of a call: vfml_conv_desc.addend, or what the device cell addend_ind holds when the kernel runs (a launch in a
+// replayed HIP graph whose per-pixel bias lives somewhere else from field to field).  Explicitly GLOBAL: a pointer that
+// went through a select or through memory would be dereferenced with flat loads.
+typedef const __attribute__((address_space(1))) float* vfml_gfptr;
+typedef const __attribute__((address_space(1))) f32x4* vfml_gf4ptr;
+__device__ __forceinline__ vfml_gfptr addend_of(const SplitArgs& a) {
+  return (vfml_gfptr)(a.addend_ind ? *a.addend_ind : a.addend);
+}
 
 union U8 {
   h16x8 v;
@@ -140,6 +150,7 @@ __device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* s
   const int gcol = n0 + c8 * 8;
   if (gcol >= a.cout) return;
   const int epi = a.epilogue;
+  const vfml_gfptr addend = addend_of(a);
   f32x4 bias4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (a.bias) {
 #pragma unroll
@@ -178,9 +189,9 @@ __device__ __forceinline__ void epilogue_rows(const SplitArgs& a, const float* s
       f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
       if (a.addend) {
         if (nvalid == 4 && a.vec_ok) {
-          add4 = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + col);
+          add4 = *(vfml_gf4ptr)(addend + (int64_t)grow * a.ld_addend + col);
         } else {
-          for (int e = 0; e < nvalid; ++e) add4[e] = a.addend[(int64_t)grow * a.ld_addend + col + e];
+          for (int e = 0; e < nvalid; ++e) add4[e] = addend[(int64_t)grow * a.ld_addend + col + e];
         }
       }
 #pragma unroll
@@ -270,6 +281,7 @@ __device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const f
     if (whole) bias4[1] = *reinterpret_cast<const f32x4*>(a.bias + gcol + 4);
   }
   const bool lowhalf = gcol < a.split;          // split is a multiple of 8 here: a unit never straddles it
+  const vfml_gfptr addend = addend_of(a);
   // The addend / aux units of a row are requested BEFORE any store of its batch: vmcnt counts in order, a load issued behind
   // a store could only be waited for together with the store's acknowledgement.
   struct RowOps {
@@ -281,8 +293,8 @@ __device__ __forceinline__ void epilogue_rows_fast_k(const SplitArgs& a, const f
     o.x0[0] = o.x0[1] = o.x1[0] = o.x1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (row >= nrows || grow >= a.M) return;
     if (a.addend) {
-      o.add[0] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol);
-      if (whole) o.add[1] = *reinterpret_cast<const f32x4*>(a.addend + (int64_t)grow * a.ld_addend + gcol + 4);
+      o.add[0] = *(vfml_gf4ptr)(addend + (int64_t)grow * a.ld_addend + gcol);
+      if (whole) o.add[1] = *(vfml_gf4ptr)(addend + (int64_t)grow * a.ld_addend + gcol + 4);
     }
     if constexpr (EPI == VFML_EPI_GRU_ZR) {
       if (!lowhalf) load_unit16(a.aux0, (int64_t)grow * a.ld_aux0 + gcol - a.split, o.x0);

@@ -520,8 +520,8 @@ extern "C" int vfml_corr_lookup_indirect_bidir(const float* const* table, const 
                                                int out_fmt, int vol_fmt, int vol_tile, void* stream) {
   VFML_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7u) == 0, "vfml_corr_lookup_indirect_bidir: null / misaligned table");
   VFML_REQUIRE(nmaps >= 1 && 2 * nmaps <= MAX_MAPS, "vfml_corr_lookup_indirect_bidir: nmaps=%d out of [1,%d]", nmaps, MAX_MAPS / 2);
-  VFML_REQUIRE(dir_coords >= 0 && dir_coords + 2 <= ld_coords && dir_out >= 0 && dir_out % 8 == 0,
-               "vfml_corr_lookup_indirect_bidir: dir_coords within a coords row, dir_out a multiple of 8 floats");
+  VFML_REQUIRE(dir_coords >= 0 && dir_coords + 2 <= ld_coords && dir_out >= 0 && (out_fmt != VFML_FMT_S16 || dir_out % 8 == 0),
+               "vfml_corr_lookup_indirect_bidir: dir_coords within a coords row, dir_out >= 0 (a multiple of 8 floats for split rows)");
   VFML_REQUIRE(dir_tab >= nmaps && (dir_tab + nmaps) * levels <= MAX_TABLE,
                "vfml_corr_lookup_indirect_bidir: dir_tab=%d (the second direction's first map in the table) out of range", dir_tab);
   return corr_lookup_impl(nullptr, table, hl, wl, ld, levels, radius, 2 * nmaps, q_per_map, coords, ld_coords, out, ld_out,

@@ -53,6 +53,7 @@ class ConvDesc(ctypes.Structure):
         ("ksplit_ws", c_void_p),
         ("proj_hi", c_void_p), ("proj_lo", c_void_p), ("proj_n", c_int32), ("proj_kp", c_int32), ("proj_scale", c_float),
         ("proj_out", c_void_p), ("ld_proj", c_int32),
+        ("addend_ind", c_void_p),
     ]
 
 
@@ -339,7 +340,7 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
            aux0=None, ld_aux0=0, aux0_off=0, aux1=None, ld_aux1=0, aux1_off=0,
            in_fmt=FMT_F32, out_fmt=FMT_F32, aux_fmt=FMT_F32, addend=None, ld_addend=0, addend_off=0,
            out_t=None, ld_out_t=0, out_t_off=0, swap_cross=False, stats_part=None, mfma=3, per_tap=False, ksplit_ws=None,
-           proj=None, proj_out=None, ld_proj=0):
+           proj=None, proj_out=None, ld_proj=0, addend_ind=None):
     """Launch vfml_conv2d. Tensors are flat float32 device buffers; *_off are float offsets into them
     (channel slices of wider NHWC buffers).  mfma: terms of the split-f16 product (3; 2 or "2w" = weights as plain
     f16; "2a" = activations as plain f16; 1 = both operands plain f16 - VFML_CONV_MFMA2 / _MFMA2A / _MFMA1).  per_tap:
@@ -367,6 +368,9 @@ def conv2d(in0, c0, ld0, n, h, w, weight, bias, cout, kh, kw, out, ldo, *, strid
     d.flags = (CONV_SWAP_CROSS if swap_cross else 0) | {3: 0, 2: CONV_MFMA2, "2a": CONV_MFMA2A, 1: CONV_MFMA1}[mfma] | (CONV_PER_TAP if per_tap else 0)
     d.stats_part = c_void_p(stats_part.data_ptr()) if stats_part is not None else None   # float64 workspace
     d.ksplit_ws = _ptr(_dev(ksplit_ws)) if ksplit_ws is not None else None      # GEMM form: second half of K (vfml.h)
+    if addend_ind is not None:       # (table tensor, entry): the device cell that holds the addend pointer (vfml.h)
+        tab, ent = addend_ind
+        d.addend_ind = c_void_p(tab.data_ptr() + 8 * ent)
     if proj is not None:
         if not isinstance(proj, SplitWeight) or proj.lo is None or proj_out is None:
             raise ValueError("proj: a SplitWeight with both planes, and proj_out")

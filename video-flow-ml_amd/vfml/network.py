@@ -317,6 +317,51 @@ class MOFNetHIP(_Holder):
         self._graphs.clear()
         self._ws.clear()
         self._feat_cache.clear()
+        self._ctx_store = None
+
+    # ------------------------------------------------------------------ per-frame context parts of the gate convolutions
+    # The context part of the four GRU gate convolutions is computed once per frame and ADDED by the gate convolutions of
+    # every iteration of every window the frame is a centre of (vfml_conv_desc.addend): [centre frames][cells][256 | 128]
+    # floats, 300 MB per 1080p window.  They live in ONE store per gate, a ring of frame slots handed out in the order frames
+    # arrive: the centre frames of a sliding job's window are then consecutive slots, and the gate convolutions - fixed
+    # launches of a replayed graph - reach them through a device cell that holds the window's first slot
+    # (vfml_conv_desc.addend_ind).  Nothing is gathered per field (round 2: twelve device copies, 0.6 GB of traffic).  The
+    # first slots are mirrored behind the ring so that a window that wraps is consecutive too; a window whose centres are not
+    # in arrival order (random access) is gathered into slots kept for that.
+    CTX_RING = 12            # >= FEATURE_CACHE_FRAMES: a cached context entry owns its slot until the ring comes round
+    CTX_GATES = (("zr1", 256), ("q1", 128), ("zr2", 256), ("q2", 128))
+
+    def _context_store(self, dev, Pn, M):
+        st = getattr(self, "_ctx_store", None)
+        if st is None or st["key"] != (str(dev), Pn) or st["M"] < M:
+            self._join_prefetch()
+            # (a coming window's centres are prefetched while the current one's are being read: two windows' worth and some)
+            R = max(self.CTX_RING, 2 * M + 4)
+            for k in [k for k in self._feat_cache if k[0] == "c"]:     # (entries of another store)
+                del self._feat_cache[k]
+            st = self._ctx_store = {
+                "key": (str(dev), Pn), "M": M, "R": R, "next": 0, "owner": [None] * R, "live": set(),
+                "serial": getattr(self, "_ctx_serial", 0) + 1,
+                "S": {g: torch.empty((R + 2 * M - 1) * Pn * co, device=dev) for g, co in self.CTX_GATES}}
+            self._ctx_serial = st["serial"]
+        return st
+
+    def _context_slot(self, st, cache_key, busy):
+        """The next slot of the ring (not one of `busy`); whoever owned it loses its cache entry."""
+        R = st["R"]
+        busy = set(busy) | st["live"]          # (the last window's centres may still be read by its launches)
+        for _ in range(R):
+            s = st["next"]
+            st["next"] = (s + 1) % R
+            if s not in busy:
+                break
+        else:
+            raise RuntimeError("context store: every slot is in use by the current window")
+        old = st["owner"][s]
+        if old is not None:
+            self._feat_cache.pop(old, None)
+        st["owner"][s] = cache_key
+        return s
 
     # ------------------------------------------------------------------ graph replay of the iteration body
     GRAPHS_KEPT = 8
@@ -544,7 +589,7 @@ class MOFNetHIP(_Holder):
                                              vt=geo.VT)
                 new += list(feats.values())
             if need_c:
-                new += list(self._frame_context(frames, need_c, keys, H, W, P, dev, h * w).values())
+                new += list(self._frame_context(frames, need_c, keys, H, W, P, dev, h * w, N - 2).values())
             if need_p:
                 new.append(self._window_pyramids(feats, keys, N, geo, dev, protect=self._pyr_busy))
             done = torch.cuda.Event()
@@ -747,12 +792,14 @@ class MOFNetHIP(_Holder):
                     self._cache_put("f", keys[j], ent)
         return out
 
-    def _frame_context(self, src, sel, keys, H, W, P, dev, Pn):
-        """Context maps (tanh | relu halves, [Pn*256] f32) of frames `sel`."""
+    def _frame_context(self, src, sel, keys, H, W, P, dev, Pn, M=1):
+        """Context maps (tanh | relu halves, [Pn*256] f32) of frames `sel`, and the context part of their gate convolutions:
+        out[j] = (map, {gate: view of the frame's slot in the gate's store}, slot)."""
         out, todo = {}, []
+        st = self._context_store(dev, Pn, max(M, len(sel)))
         for j in sel:
             ent = self._cache_get("c", keys[j]) if keys is not None else None
-            if ent is not None:
+            if ent is not None and ent[3] == st["serial"]:
                 out[j] = ent
             else:
                 todo.append(j)
@@ -765,19 +812,24 @@ class MOFNetHIP(_Holder):
             AF = hip.FMT_S16 if self._split() else hip.FMT_F32
             self._encoder("cnet", frames, m, H, W, P, dev, ctx, 256, 0, hip.EPI_TANH_RELU, self.hidden_dim, out_fmt=AF)
             h8, w8 = H // 8, W // 8
+            R, Mst = st["R"], st["M"]
             for i, j in enumerate(todo):
                 cx = ctx[i * Pn * 256:(i + 1) * Pn * 256]
-                # context part of the GRU gate convolutions (+ bias), per pass: [z|r] (256) and q (128)
+                busy = {e[2] for e in out.values()}
+                slot = self._context_slot(st, ("c", keys[j]) if keys is not None else None, busy)
+                # context part of the GRU gate convolutions (+ bias), per pass: [z|r] (256) and q (128), into the frame's slot
                 add = {}
                 for k, (kh, kw) in (("1", (1, 5)), ("2", (5, 1))):
                     for g, co in (("zr", 256), ("q", 128)):
                         wgt, b = P[f"update_block.gru.conv{g}{k}.ctx"]
-                        a = torch.empty(Pn * co, device=dev)
-                        hip.conv2d(cx, 128, 256, 1, h8, w8, wgt, b, co, kh, kw, a, co, in0_off=128,
+                        S = st["S"][g + k]
+                        hip.conv2d(cx, 128, 256, 1, h8, w8, wgt, b, co, kh, kw, S, co, in0_off=128, out_off=slot * Pn * co,
                                    pad_h=kh // 2, pad_w=kw // 2, in_fmt=AF,
                                    mfma=self._nm(f"update_block.gru.conv{g}{k}.ctx") if self._split() else 3)
-                        add[g + k] = a
-                out[j] = (cx, add)
+                        add[g + k] = S[slot * Pn * co:(slot + 1) * Pn * co]
+                        if slot < Mst - 1:          # the ring's first slots again behind it: a window that wraps stays consecutive
+                            S[(R + slot) * Pn * co:(R + slot + 1) * Pn * co].copy_(add[g + k])
+                out[j] = (cx, add, slot, st["serial"])
                 if keys is not None:
                     self._cache_put("c", keys[j], out[j])
         return out
@@ -828,15 +880,33 @@ class MOFNetHIP(_Holder):
             GLD, Z, RH, HH, INP, MF, MT = 768, 0, 128, 256, 384, 512, 640
             G = self._buf("gru_state", MP * GLD, dev)
             # K2 context encoder on the centre frames -> h = tanh(first half), inp = relu(second half)
-            ctx = self._frame_context(src, list(range(1, N - 1)), keys, H, W, P, dev, Pn)
+            ctx = self._frame_context(src, list(range(1, N - 1)), keys, H, W, P, dev, Pn, M)
             Gv = G.view(MP, GLD)
-            gate_add = {g + k: self._buf(f"gate_add_{g}{k}", MP * co, dev)
-                        for k in ("1", "2") for g, co in (("zr", 256), ("q", 128))}
-            for c in range(1, N - 1):
-                Gv[(c - 1) * Pn:c * Pn, HH:HH + 256].copy_(ctx[c][0].view(Pn, 256))
-                for name, buf in gate_add.items():
-                    n_el = ctx[c][1][name].numel()
-                    buf[(c - 1) * n_el:c * n_el].copy_(ctx[c][1][name])
+            for c in range(1, N - 1):       # h = tanh half of the context map (the relu half reaches the gates as their addends)
+                Gv[(c - 1) * Pn:c * Pn, HH:HH + 128].copy_(ctx[c][0].view(Pn, 256)[:, :128])
+            # the gates' context parts: the centre frames' slots, consecutive in a sliding job (through the mirror when the ring
+            # wraps) - else gathered into the store's spare slots
+            st = self._ctx_store
+            RING, Mst = st["R"], st["M"]
+            slots = [ctx[c][2] for c in range(1, N - 1)]
+            st["live"] = set(slots)
+            first = slots[0]
+            # (the exact-f32 kernel takes the pointer itself - a captured launch needs it fixed: always the gathered copy)
+            # (A/B switch: VFML_CTX_GATHER=1 gathers every window, as round 2 did)
+            if (not self._split() or os.environ.get("VFML_CTX_GATHER", "0") == "1" or
+                    not all(s == first + i or (first + i >= RING and s == first + i - RING and s < Mst - 1)
+                            for i, s in enumerate(slots))):
+                first = RING + Mst - 1
+                for i, c in enumerate(range(1, N - 1)):
+                    for name, co in self.CTX_GATES:
+                        st["S"][name][(first + i) * Pn * co:(first + i + 1) * Pn * co].copy_(ctx[c][1][name])
+            gate_add = {name: st["S"][name] for name, _ in self.CTX_GATES}
+            gate_off = {name: first * Pn * co for name, co in self.CTX_GATES}
+            gate_ind = None
+            if self._split():      # (the exact-f32 kernel takes the pointer itself)
+                cells = self._buf("gate_add_cells", 8, dev, torch.int64)
+                hip.ptr_table_set(cells, [st["S"][name][gate_off[name]:] for name, _ in self.CTX_GATES])
+                gate_ind = {name: (cells, i) for i, (name, _) in enumerate(self.CTX_GATES)}
 
             corr = self._buf("corr", MP * 2 * cor_p, dev, zero=True)   # pad channels stay zero
             c1 = self._buf("c1", MP * 256, dev)
@@ -957,6 +1027,8 @@ class MOFNetHIP(_Holder):
                                    in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                    epilogue=hip.EPI_GRU_ZR, split=128, aux0=G, ld_aux0=GLD, aux0_off=HH,
                                    addend=gate_add["zr" + k], ld_addend=256, in_fmt=AF, out_fmt=AF, aux_fmt=AF,
+                                   addend_off=0 if gate_ind else gate_off["zr" + k],
+                                   addend_ind=gate_ind["zr" + k] if gate_ind else None,
                                    mfma=mf(f"{ub}.gru.convzr{k}.iter"))
                         wgt, _ = P[f"{ub}.gru.convq{k}.iter"]
                         # h = (1 - z) h + z tanh(conv([r*h | motion | temporal]) + context part), in place
@@ -964,6 +1036,8 @@ class MOFNetHIP(_Holder):
                                    in1=G, c1=256, ld1=GLD, in1_off=MF, pad_h=kh // 2, pad_w=kw // 2,
                                    epilogue=hip.EPI_GRU_Q, aux0=G, ld_aux0=GLD, aux0_off=Z,
                                    aux1=G, ld_aux1=GLD, aux1_off=HH, addend=gate_add["q" + k], ld_addend=128,
+                                   addend_off=0 if gate_ind else gate_off["q" + k],
+                                   addend_ind=gate_ind["q" + k] if gate_ind else None,
                                    in_fmt=AF, out_fmt=AF, aux_fmt=AF, mfma=mf(f"{ub}.gru.convq{k}.iter"))
                     # flow head
                     wgt, b = P[f"{ub}.flow_head.conv1"]
