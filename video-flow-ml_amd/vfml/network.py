@@ -924,16 +924,17 @@ class MOFNetHIP(_Holder):
             # and those are named by two device tables.  With cfg.use_graph the sequence is captured into a HIP
             # graph the second time a configuration is seen and replayed from then on (~250 launches per field
             # become one; same kernels, same order: bit-identical results).
-            tab_f = self._buf("pyr_table_f", 64, dev, torch.int64)
-            tab_b = self._buf("pyr_table_b", 64, dev, torch.int64)
-            hip.ptr_table_set(tab_f, [p for m in pyrs["f"] for p in m])
-            hip.ptr_table_set(tab_b, [p for m in pyrs["b"] for p in m])
             # both directions behind one another in one table: the two lookups of an iteration as ONE launch (at most 8 maps;
             # A/B switch VFML_LOOKUP_BIDIR=0)
             bidir = 2 * M <= 8 and 2 * M * L <= 48 and os.environ.get("VFML_LOOKUP_BIDIR", "1") != "0"
             if bidir:
                 tab_fb = self._buf("pyr_table_fb", 64, dev, torch.int64)
                 hip.ptr_table_set(tab_fb, [p for d in ("f", "b") for m in pyrs[d] for p in m])
+            else:
+                tab_f = self._buf("pyr_table_f", 64, dev, torch.int64)
+                tab_b = self._buf("pyr_table_b", 64, dev, torch.int64)
+                hip.ptr_table_set(tab_f, [p for m in pyrs["f"] for p in m])
+                hip.ptr_table_set(tab_b, [p for m in pyrs["b"] for p in m])
             no = 1 if pick_only and not self.tri_frame else M
             nflows = 1 if pick_only and not self.tri_frame else 2 * M
             up_fixed = self._buf("up_out", nflows * H * W * 2, dev)
