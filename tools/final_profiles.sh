@@ -17,7 +17,7 @@ step "bench corr32";      timeout -k 10 300 python3 bench.py --corr-volume f32 -
 step "bench prefetch off"; VFML_PREFETCH=0 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-jobs > $OUT/bench_pf0.log 2>&1 && tail -1 $OUT/bench_pf0.log > $OUT/${TAG}_bench_prefetch_off.json || exit 1
 step "bench memflow";     timeout -k 10 300 python3 bench.py --workload memflow1080p --steps 18 --no-cpu-baseline > $OUT/bench_memflow.log 2>&1 && tail -1 $OUT/bench_memflow.log > $OUT/${TAG}_memflow1080p_bench.json || exit 1
 step "bench bof720p";     timeout -k 10 300 python3 bench.py --workload bof720p --steps 32 --no-cpu-baseline > $OUT/bench_bof.log 2>&1 && tail -1 $OUT/bench_bof.log > $OUT/${TAG}_bof720p_bench.json || exit 1
-step "bench 4k tile";     timeout -k 10 300 python3 bench.py --workload mof4k-tile --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_4k.log 2>&1 && tail -1 $OUT/bench_4k.log > $OUT/${TAG}_mof4k_tile_bench.json || exit 1
+step "bench 4k tile";     timeout -k 10 300 python3 bench.py --workload mof4k-tile --steps 12 --warmup 4 --no-cpu-baseline > $OUT/bench_4k.log 2>&1 && tail -1 $OUT/bench_4k.log > $OUT/${TAG}_mof4k_tile_bench.json || exit 1
 step "rocprofv3 stats (as shipped)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-jobs > $OUT/prof.log 2>&1 || exit 1
 grep "^{\"metric\"" $OUT/prof.log | tail -1 > $OUT/${TAG}_bench_profiled.json
