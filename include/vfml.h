@@ -287,6 +287,17 @@ int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream
  * rows: [n*h*w][32] split rows (VFML_FMT_S16, 32-byte aligned). */
 int vfml_flow_rows7(const float* flow, int n, int h, int w, float* rows, void* stream);
 
+/* The flow half of the motion encoder as one launch (K6, BasicMotionEncoder.convf1 + convf2 with their ReLUs), for plans that
+ * run both layers with ONE MFMA per product (VFML_CONV_MFMA1: plain f16 operands, f32 accumulate):
+ *   out[p][0..63] = relu(conv3x3(relu(conv7x7(flow) + b1)) + b2),   flow: [n*h*w][4] f32,
+ * out: split rows (VFML_FMT_S16), 64 channels from out[p * ld_out] (32-byte aligned, ld_out % 8 == 0).  w1_hi: the f16 hi
+ * plane [128][224] of convf1's weights * w1_scale in the vfml_flow_rows7 layout (K = ky * 32 + kx * 4 + c), w2_hi: the hi
+ * plane [64][1152] of convf2's * w2_scale in VFML_KORDER_CBLOCK64 order (K = (c / 64) * 576 + (ky * 3 + kx) * 64 + c % 64);
+ * kp1 / kp2 their row pitches in halves (224 / 1152).  The 128-channel map between the two layers lives in LDS only; the
+ * result is bit-identical to vfml_flow_rows7 + two vfml_conv2d_split calls with VFML_CONV_MFMA1. */
+int vfml_flow_half(const float* flow, int n, int h, int w, const void* w1_hi, int kp1, float w1_scale, const float* b1,
+                   const void* w2_hi, int kp2, float w2_scale, const float* b2, float* out, int ld_out, void* stream);
+
 /* A 3x3 "same" convolution with FOUR output channels as a 1x1 convolution to 36 (tap-major: column (ky*3+kx)*4 + o holds
  * sum_c w[o][c][ky][kx] x[.][c]) followed by this pass: out[p][o] = bias[o] + sum over the nine taps inside the image of
  * t[p + (ky-1) w + (kx-1)][(ky*3+kx)*4 + o], taps in ky-major order.  The update block's flow head (256 -> 4) costs nine

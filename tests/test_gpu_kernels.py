@@ -989,6 +989,45 @@ def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
         hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)
 
 
+@pytest.mark.parametrize("n,H,W", [(3, 135, 240), (1, 5, 31), (2, 16, 24)])
+def test_flow_half_kernel_is_the_two_convolutions(gpu, n, H, W):
+    """vfml_flow_half (7x7 over the flow + ReLU + 3x3 + ReLU, the 128-channel map in LDS) == vfml_flow_rows7 + the two
+    one-MFMA convolutions, bit for bit - ragged tiles, image borders (the zero padding of the 128-channel map, not of the
+    flow) - and within plain-f16 tolerance of the float64 result."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(H * W + n)
+    flow = (torch.randn(n, 4, H, W, generator=g) * 3.0)
+    w1 = torch.randn(128, 4, 7, 7, generator=g) / math.sqrt(4 * 49)
+    b1 = torch.randn(128, generator=g) * 0.1
+    w2 = torch.randn(64, 128, 3, 3, generator=g) / math.sqrt(128 * 9)
+    b2 = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(flow.double(), w1.double(), b1.double(), padding=3)), w2.double(), b2.double(), padding=1)).float()
+    P = n * H * W
+    # the network's packing of the two layers (vfml/network.py _pack): rows7 layout, 64-channel-block order
+    w7 = torch.zeros(128, 32, 7, 1)
+    w7[:, :28, :, 0] = w1.permute(0, 3, 1, 2).reshape(128, 28, 7)
+    W1 = as_weight(pack_conv_weight(w7, cblock=True), 128, "f16x3", order=hip.KORDER_CBLOCK)
+    W2 = as_weight(pack_conv_weight(w2, cblock=64), 64, "f16x3", order=hip.KORDER_CBLOCK64)
+    flow4 = nhwc(flow)
+    # three launches
+    rows = torch.zeros(P * 32, device=gpu)
+    hip.flow_rows7(flow4, n, H, W, rows)
+    f1 = torch.zeros(P * 128, device=gpu)
+    hip.conv2d(rows, 32, 32, n, H, W, W1, b1.cuda(), 128, 7, 1, f1, 128, pad_h=3, epilogue=hip.EPI_RELU, in_fmt=hip.FMT_S16,
+               out_fmt=hip.FMT_S16, mfma=1)
+    two = torch.full((P * 256,), 3.0, device=gpu)
+    hip.conv2d(f1, 128, 128, n, H, W, W2, b2.cuda(), 64, 3, 3, two, 256, out_off=192, pad_h=1, pad_w=1, epilogue=hip.EPI_RELU,
+               in_fmt=hip.FMT_S16, out_fmt=hip.FMT_S16, mfma=1)
+    # one launch
+    one = torch.full((P * 256,), 3.0, device=gpu)
+    hip.flow_half(flow4, n, H, W, W1, b1.cuda(), W2, b2.cuda(), one, 256, out_off=192)
+    assert torch.equal(one.view(torch.int32), two.view(torch.int32))
+    got = s16_decode(one.view(P, 256)[:, 192:].contiguous().reshape(-1), P, 64, 64)
+    got = got.view(n, H, W, 64).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) < 4e-3, rel_err(got, ref)
+
+
 def test_bidirectional_lookup_is_two_lookups(gpu):
     """vfml_corr_lookup_indirect_bidir == the forward and the backward lookup as two launches, bit for bit (fewer query maps
     than the table holds per direction, split-row output, tiled volumes with an f16 level)."""

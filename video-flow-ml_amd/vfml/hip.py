@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFML_LIB") or os.path.join(_HERE, "libvfml_hip.so")   # VFML_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "stem.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "stem.hip", "flow_half.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
 
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
@@ -149,6 +149,8 @@ def lib():
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_tapsum3x3_update.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p,
                                         c_int, c_void_p, c_int, c_int, c_void_p]
+    L.vfml_flow_half.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float,
+                                 c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
     L.vfml_flow_rows7.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     L.vfml_tapsum3x3.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, ctypes.c_int64, c_void_p]
@@ -173,7 +175,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect", "vfml_corr_lookup_indirect_bidir",
-    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_tapsum3x3_update", "vfml_flow_rows7",
+    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_tapsum3x3_update", "vfml_flow_rows7", "vfml_flow_half",
     "vfml_convex_upsample", "vfml_stem7x7s2", "vfml_stem7x7s2_chunks", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -646,6 +648,14 @@ def tapsum3x3(t, ld_t, bias, n, h, w, out, parts=1, part_stride=0):
     that many maps part_stride floats apart whose sum is meant (conv2d(..., proj_out=))."""
     _check(lib().vfml_tapsum3x3(_ptr(_dev(t)), ld_t, _ptr(bias) if bias is not None else None, n, h, w, _ptr(_dev(out)),
                                 parts, part_stride, _stream()), "vfml_tapsum3x3")
+
+
+def flow_half(flow, n, h, w, w1, b1, w2, b2, out, ld_out, out_off=0):
+    """relu(convf2(relu(convf1(flow)))) of the motion encoder as one launch (include/vfml.h vfml_flow_half): w1 / w2 the
+    layers' SplitWeights (rows7 layout / 64-channel-block order), plain f16 products."""
+    _check(lib().vfml_flow_half(_ptr(_dev(flow)), n, h, w, c_void_p(w1.hi.data_ptr()), w1.kp, w1.scale, _ptr(_dev(b1)),
+                                c_void_p(w2.hi.data_ptr()), w2.kp, w2.scale, _ptr(_dev(b2)), _ptr(_dev(out), out_off), ld_out,
+                                _stream()), "vfml_flow_half")
 
 
 def tapsum3x3_update(t, ld_t, bias, n, h, w, coords1, parts=1, part_stride=0, flow_a=None, ld_a=0, flow_a_off=0, flow_b=None,

@@ -953,6 +953,7 @@ class MOFNetHIP(_Holder):
                         branch = self._side2[dev] = torch.cuda.Stream(device=dev)
                 # (A/B switch: VFML_FUSE_HEAD=0 runs the flow head's two layers as two launches)
                 fuse_head = os.environ.get("VFML_FUSE_HEAD", "1") != "0" and AF == hip.FMT_S16
+                fuse_flow = os.environ.get("VFML_FUSE_FLOW", "1") != "0" and AF == hip.FMT_S16      # (A/B switch, as above)
                 for it in range(cfg.decoder_depth):
                     # pick_only: the caller takes flow M (the backward flow of the first centre frame - the reference's
                     # `[0, shape[1]//2]`).  Going back from the last iteration, centre 0's result depends on one centre
@@ -967,6 +968,12 @@ class MOFNetHIP(_Holder):
                     # a captured graph, two branches).  Same kernels on the same inputs: bit-identical fields.
                     def flow_half(nm=nm):
                         wgt, b = P[f"{ub}.encoder.convf1"]
+                        wgt2, b2 = P[f"{ub}.encoder.convf2"]
+                        if (fuse_flow and self._rows7 and mf(f"{ub}.encoder.convf1") == 1 and mf(f"{ub}.encoder.convf2") == 1
+                                and getattr(wgt2, "order", None) == hip.KORDER_CBLOCK64 and wgt.kp == 224 and wgt2.kp == 1152):
+                            # both layers in one launch, the 128-channel map between them in LDS (vfml_flow_half; same bits)
+                            hip.flow_half(flow4, nm, h, w, wgt, b, wgt2, b2, cf, 256, out_off=192)
+                            return
                         if self._rows7:
                             hip.flow_rows7(flow4, nm, h, w, frows)
                             hip.conv2d(frows, 32, 32, nm, h, w, wgt, b, 128, 7, 1, f1, 128, pad_h=3, epilogue=hip.EPI_RELU,
@@ -1086,7 +1093,7 @@ class MOFNetHIP(_Holder):
                                                 up_fixed, out_off=(d * M + c) * H * W * 2)
 
             gkey = (H, W, N, M, bool(tri_batch), bool(pick_only), cfg.decoder_depth, L, R, self._plan_key(), vol16,
-                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"), os.environ.get("VFML_FUSE_HEAD", "1"), bidir)
+                    self._packed_serial, str(dev), os.environ.get("VFML_FLOW_BRANCH", "0"), os.environ.get("VFML_FUSE_HEAD", "1"), bidir, os.environ.get("VFML_FUSE_FLOW", "1"))
             self._pre_body = torch.cuda.Event()
             self._pre_body.record(torch.cuda.current_stream(dev))      # (what a prefetch of the next window waits for)
             self._run_body(body, gkey, dev)
