@@ -287,6 +287,16 @@ int vfml_ptr_table_set(void* table, const void* const* ptrs, int n, void* stream
  * rows: [n*h*w][32] split rows (VFML_FMT_S16, 32-byte aligned). */
 int vfml_flow_rows7(const float* flow, int n, int h, int w, float* rows, void* stream);
 
+/* The encoders' 64 -> 64 channel 3x3 convolution (stride 1, padding 1; K2: the residual blocks of `layer1`) with persistent
+ * workgroups that keep the weights in registers and one input patch per 4 x 32-pixel tile in LDS:
+ *   out[p][0..63] = conv3x3(in)[p] + bias   (plain f32 rows, ldo floats apart),
+ * in: split rows (VFML_FMT_S16), the 64 channels from in[p * ld_in]; w_hi / w_lo: the f16 planes [64][576] of the weights *
+ * w_scale in VFML_KORDER_CBLOCK order; stats_part (optional): as vfml_conv_desc.stats_part with VFML_STATS_ROWS_S16 (one
+ * {sum, sum of squares} pair per 32 consecutive pixels and channel).  The image width must be a multiple of 32.  Full split
+ * product, the K order of vfml_conv2d_split: the result and the partial sums are bit-identical to that call's. */
+int vfml_conv3x3_c64(const float* in, int ld_in, int n, int h, int w, const void* w_hi, const void* w_lo, int kp, float w_scale,
+                     const float* bias, float* out, int ldo, double* stats_part, void* stream);
+
 /* The flow half of the motion encoder as one launch (K6, BasicMotionEncoder.convf1 + convf2 with their ReLUs), for plans that
  * run both layers with ONE MFMA per product (VFML_CONV_MFMA1: plain f16 operands, f32 accumulate):
  *   out[p][0..63] = relu(conv3x3(relu(conv7x7(flow) + b1)) + b2),   flow: [n*h*w][4] f32,

@@ -989,6 +989,39 @@ def test_tapsum3x3_is_the_3x3_convolution(gpu, n, H, W):
         hip.tapsum3x3(tp.cuda().reshape(-1), 34, None, n, H, W, out)
 
 
+@pytest.mark.parametrize("n,H,W", [(1, 540, 960), (2, 6, 64), (1, 9, 32)])
+def test_encoder_c64_kernel_is_the_general_convolution(gpu, n, H, W):
+    """vfml_conv3x3_c64 (persistent workgroups, weights in registers, one patch per tile) == vfml_conv2d_split on the same
+    split-row input, bit for bit, and so are the norm partial sums; ragged tile rows, image borders."""
+    from vfml import hip
+    from vfml.weights import pack_conv_weight
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(n, 64, H, W, generator=g)
+    wt = torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(64 * 9)
+    b = torch.randn(64, generator=g) * 0.1
+    P = n * H * W
+    src = torch.zeros(P * 64, device=gpu)
+    hip.to_s16(nhwc(x), P, 64, 64, src, 64)
+    Wt = as_weight(pack_conv_weight(wt, cblock=True), 64, "f16x3", order=hip.KORDER_CBLOCK)
+    chunks = P // 32
+    outs, parts = [], []
+    for fused in (False, True):
+        out = torch.full((P * 64,), float("nan"), device=gpu)
+        part = torch.full((chunks * 64 * 2,), float("nan"), dtype=torch.float64, device=gpu)
+        if fused:
+            hip.conv3x3_c64(src, 64, n, H, W, Wt, b.cuda(), out, 64, stats_part=part)
+        else:
+            hip.conv2d(src, 64, 64, n, H, W, Wt, b.cuda(), 64, 3, 3, out, 64, pad_h=1, pad_w=1, stats_part=part, in_fmt=hip.FMT_S16)
+        outs.append(out)
+        parts.append(part)
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(parts[1]).all()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.equal(parts[0], parts[1])
+    ref = F.conv2d(x[:1, :, :8].double(), wt.double(), b.double(), padding=1)[:, :, :6].float()
+    got = from_nhwc(outs[1], n, H, W, 64)[:1, :, :6]
+    assert rel_err(got, ref) < CONV_TOL["f16x3"], rel_err(got, ref)
+
+
 @pytest.mark.parametrize("n,H,W", [(3, 135, 240), (1, 5, 31), (2, 16, 24)])
 def test_flow_half_kernel_is_the_two_convolutions(gpu, n, H, W):
     """vfml_flow_half (7x7 over the flow + ReLU + 3x3 + ReLU, the 128-channel map in LDS) == vfml_flow_rows7 + the two

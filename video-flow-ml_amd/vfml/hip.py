@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFML_LIB") or os.path.join(_HERE, "libvfml_hip.so")   # VFML_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "stem.hip", "flow_half.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_gemm_split.hip", "conv_gemm_tapx.hip", "stem.hip", "flow_half.hip", "enc_conv.hip", "norm_pool.hip", "flow_ops.hip", "effects.hip"]
 
 STATS_ROWS_F32, STATS_ROWS_S16 = 128, 32    # pixels per stats_part block (include/vfml.h VFML_STATS_ROWS_*)
 EPI_NONE, EPI_RELU, EPI_TANH, EPI_SIGMOID, EPI_TANH_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ADD_AUX = range(8)
@@ -149,6 +149,8 @@ def lib():
     L.vfml_ptr_table_set.argtypes = [c_void_p, POINTER(c_void_p), c_int, c_void_p]
     L.vfml_tapsum3x3_update.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p,
                                         c_int, c_void_p, c_int, c_int, c_void_p]
+    L.vfml_conv3x3_c64.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_void_p]
     L.vfml_flow_half.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float,
                                  c_void_p, c_void_p, c_int, c_void_p]
     L.vfml_coords_init.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
@@ -175,7 +177,7 @@ EXPORTS = [
     "vfml_conv2d", "vfml_conv2d_split", "vfml_split_f16", "vfml_to_s16", "vfml_softmax_rows_s16", "vfml_softmax_rows_f16", "vfml_transpose_to_s16", "vfml_add_to_s16",
     "vfml_transpose_split_f16", "vfml_frames_to_nhwc4", "vfml_instnorm_workspace_bytes", "vfml_instnorm_stats",
     "vfml_instnorm_apply", "vfml_instnorm_finalize", "vfml_instnorm_finalize_workspace_bytes", "vfml_avgpool2x2", "vfml_corr_lookup", "vfml_corr_lookup_indirect", "vfml_corr_lookup_indirect_bidir",
-    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_tapsum3x3_update", "vfml_flow_rows7", "vfml_flow_half",
+    "vfml_ptr_table_set", "vfml_coords_update", "vfml_coords_init", "vfml_tapsum3x3", "vfml_tapsum3x3_update", "vfml_flow_rows7", "vfml_flow_half", "vfml_conv3x3_c64",
     "vfml_convex_upsample", "vfml_stem7x7s2", "vfml_stem7x7s2_chunks", "vfml_flow_lod", "vfml_flow_encode", "vfml_taa_blend", "vfml_flow_quality_map", "vfml_last_error", "vfml_abi_version",
 ]
 
@@ -648,6 +650,16 @@ def tapsum3x3(t, ld_t, bias, n, h, w, out, parts=1, part_stride=0):
     that many maps part_stride floats apart whose sum is meant (conv2d(..., proj_out=))."""
     _check(lib().vfml_tapsum3x3(_ptr(_dev(t)), ld_t, _ptr(bias) if bias is not None else None, n, h, w, _ptr(_dev(out)),
                                 parts, part_stride, _stream()), "vfml_tapsum3x3")
+
+
+def conv3x3_c64(src, ld_in, n, h, w, weight, bias, out, ldo, stats_part=None, src_off=0):
+    """The encoders' 64 -> 64 channel 3x3 convolution over split rows with its norm partial sums (include/vfml.h
+    vfml_conv3x3_c64; image width a multiple of 32, weights in KORDER_CBLOCK order)."""
+    _check(lib().vfml_conv3x3_c64(_ptr(_dev(src), src_off), ld_in, n, h, w, c_void_p(weight.hi.data_ptr()),
+                                  c_void_p(weight.lo.data_ptr()), weight.kp, weight.scale,
+                                  _ptr(_dev(bias)) if bias is not None else None, _ptr(_dev(out)), ldo,
+                                  c_void_p(stats_part.data_ptr()) if stats_part is not None else None, _stream()),
+           "vfml_conv3x3_c64")
 
 
 def flow_half(flow, n, h, w, w1, b1, w2, b2, out, ld_out, out_off=0):

@@ -424,6 +424,8 @@ class MOFNetHIP(_Holder):
         # encoders on another stream - prefetch_frames - is ordered against the main stream's use by _join_prefetch)
         fold_ws = self._buf("enc_foldws", min(n, 8) * 64 * 128 * 2, dev, torch.float64) if split_prec else None
 
+        enc_c64 = os.environ.get("VFML_ENC_C64", "1") != "0"         # (A/B switch: the general kernel for layer1's convolutions)
+
         def conv_stats(src, c, hh_, ww_, name, planes, dst, slot, k, stride=1, pad=0, src_fmt=hip.FMT_F32):
             wgt, b = P[name]
             nm = self._nm(name) if split_prec else 3
@@ -436,8 +438,13 @@ class MOFNetHIP(_Holder):
                 return stats_of(dst, hw, planes, slot)
             chunks = (hw + rows - 1) // rows
             part = parts[slot * part_len:]
-            hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
-                       stats_part=part, mfma=nm, in_fmt=src_fmt)
+            if (enc_c64 and c == 64 and planes == 64 and k == 3 and stride == 1 and pad == 1 and nm == 3 and src_fmt == hip.FMT_S16
+                    and ww_ % 32 == 0 and getattr(wgt, "order", None) == hip.KORDER_CBLOCK and wgt.kp == 576 and wgt.lo is not None):
+                # the residual blocks of layer1: persistent workgroups, weights in registers, one patch per tile (same bits)
+                hip.conv3x3_c64(src, c, n, hh_, ww_, wgt, b, dst, planes, stats_part=part)
+            else:
+                hip.conv2d(src, c, c, n, hh_, ww_, wgt, b, planes, k, k, dst, planes, stride=stride, pad_h=pad, pad_w=pad,
+                           stats_part=part, mfma=nm, in_fmt=src_fmt)
             s = st[slot * n * 128 * 2:]
             hip.instnorm_finalize(part, n, chunks, planes, hw, s, workspace=fold_ws)
             return s
